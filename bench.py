@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s (and rays/s) of the wavefront path tracer.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the configuration `metric` is quoted on): synthetic procedural
+height-field mesh, 1 002 528 triangles, Lambertian/metal materials under the (placeholder) sky,
+1920x1080, 256 spp per GPU, max depth 50.  One "step" = one full render of that frame on every GPU:
+rank r renders the global sample indices r, r+N, r+2N, ... (scene replicated in each GPU's HBM), the
+per-GPU radiance-sum buffers are combined with one RCCL sum-reduce, rank 0 resolves the mean.  Work
+per GPU is fixed as N grows ("weak"): the frame gets 256*N spp in the same time.
+
+value = W*H*spp_per_gpu*N / t_step / 1e6 (Msamples/s, whole job), inputs resident in HBM.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="heightfield_1m", choices=["heightfield_1m", "cover", "textured_5m"])
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (default: the config's)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_workload(name, width, height, spp):
+    from rt_amd import scenes
+    if name == "heightfield_1m":
+        desc = scenes.heightfield_scene(quads=708)
+        cam = scenes.heightfield_camera(width, height, spp or 256, 50)
+        label = "S3 height-field 1002528 tris, widecam"
+    elif name == "cover":
+        desc = scenes.cover_scene()
+        cam = scenes.cover_camera(width, height, spp or 1024, 50, defocus=True)
+        label = "S1 RTIOW cover scene (447 spheres + checker ground), cam2"
+    else:
+        desc = scenes.textured_scene()
+        cam = scenes.cover_camera(width, height, spp or 1024, 50, defocus=False)
+        cam = scenes.heightfield_camera(width, height, spp or 1024, 50)
+        label = "S4 textured terrain + icosphere instances ~5.0M tris, widecam"
+    return desc, cam, label
+
+
+def cpu_baseline(desc, cam, target_seconds):
+    """Times the oracle (kind "port": C f64 restatement, per-pixel recursion, BVH with one primitive
+    per leaf traversed near-first WITHOUT distance pruning, like bvh 0.10's iterator) on the host
+    cores, on a bounded sample: a band of pixel rows around the image centre at 1 spp."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    t0 = time.time()
+    orc = O.OracleScene(desc)
+    build_s = time.time() - t0
+    mid = cam.height // 2
+    # probe 2 rows, then size the band
+    t0 = time.time()
+    orc.render(cam, 1, seed=1, mode=O.BVH_NOPRUNE, nthreads=cores, rows=(mid, min(cam.height, mid + 2)))
+    probe = max(time.time() - t0, 1e-3) / 2.0
+    rows = int(max(2, min(cam.height, target_seconds / probe)))
+    y0 = max(0, mid - rows // 2)
+    y1 = min(cam.height, y0 + rows)
+    t0 = time.time()
+    _, st = orc.render(cam, 1, seed=1, mode=O.BVH_NOPRUNE, nthreads=cores, rows=(y0, y1), with_stats=True)
+    dt = time.time() - t0
+    samples = (y1 - y0) * cam.width
+    # the same band with distance pruning, for the record (not the reference's behaviour)
+    t0 = time.time()
+    orc.render(cam, 1, seed=1, mode=O.BVH_PRUNE, nthreads=cores, rows=(y0, y1))
+    dt_prune = time.time() - t0
+    orc.close()
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"rows {y0}..{y1} of the same {cam.width}x{cam.height} frame at 1 spp ({samples} samples, {dt:.1f} s)",
+            "rays_per_s": float(st["ray_segments"]) / dt, "oracle_bvh_build_s": build_s,
+            "value_with_distance_pruning": samples / dt_prune / 1e6}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rt_amd import World, _abi
+    from rt_amd._lib import check, lib
+
+    desc, cam, label = make_workload(args.workload, args.width, args.height, args.spp)
+    spp = cam.samples_per_pixel
+    t0 = time.time()
+    w = World.build(desc, device=local_rank)
+    info = w.info()
+    create_s = time.time() - t0
+    W, H = cam.width, cam.height
+    rgb_sum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    rgb_mean = torch.zeros_like(rgb_sum)
+    L = lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(collect=False, spp_override=None):
+        stream = torch.cuda.current_stream().cuda_stream
+        o = cam.opts(spp=spp_override or spp, sample_offset=rank, sample_stride=world, seed=2024, device=local_rank,
+                     collect_stats=collect)
+        st = _abi.one(_abi.stats_dt)
+        rgb_sum.zero_()
+        check(L.rt_render_accumulate_device(w._h, _abi.ptr(cam.rec), _abi.ptr(o), C.c_void_p(rgb_sum.data_ptr()),
+                                            C.c_void_p(stream), _abi.ptr(st)))
+        if world > 1:
+            dist.reduce(rgb_sum, dst=0, op=dist.ReduceOp.SUM)       # RCCL sum-reduce over xGMI
+        if rank == 0:
+            check(L.rt_resolve_device(C.c_void_p(rgb_sum.data_ptr()), C.c_void_p(rgb_mean.data_ptr()), rgb_sum.numel(),
+                                      (spp_override or spp) * world, local_rank, C.c_void_p(stream)))
+        return st[0]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    seg = torch.tensor([float(sum(int(s["ray_segments"]) for s in stats))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        samples_per_step = W * H * spp * world
+        value = samples_per_step / (dt / args.steps) / 1e6
+        rays_per_s = float(seg.item()) / dt
+        # ---- roofline of the dominant kernel (k_trace), from HIP events recorded by the library on
+        # the stream the kernel runs on, over the timed steps of rank 0
+        trace_s = sum(float(s["seconds_trace"]) for s in stats)
+        shade_s = sum(float(s["seconds_shade"]) for s in stats)
+        n_launch = sum(int(s["trace_launches"]) for s in stats)
+        seg0 = sum(int(s["ray_segments"]) for s in stats)
+        prim_s = sum(float(s["seconds_trace_primary"]) for s in stats)
+        prim_seg = sum(int(s["primary_segments"]) for s in stats)
+        bounce_rays_per_s = (seg0 - prim_seg) / max(trace_s - prim_s, 1e-12)
+        # visits per segment from one instrumented (untimed) low-spp render of the same frame
+        sst = step(collect=True, spp_override=min(spp, 4))
+        torch.cuda.synchronize()
+        v_n = int(sst["nodes_visited"]) / max(1, int(sst["ray_segments"]))
+        v_p = int(sst["prims_tested"]) / max(1, int(sst["ray_segments"]))
+        prim_bytes = info["tri_bytes"] if len(desc.triangles) >= len(desc.spheres) else info["sphere_bytes"]
+        bytes_per_seg = 48 + 28 + v_n * info["node_bytes"] + v_p * prim_bytes
+        achieved = seg0 * bytes_per_seg / trace_s / 1e9 if trace_s > 0 else 0.0
+        img = rgb_mean.cpu().numpy()
+        out = {
+            "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "width": W, "height": H, "spp_per_gpu": spp, "global_spp": spp * world,
+                       "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
+            "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_trace",
+                         "avg_launch_ms": trace_s / max(1, n_launch) * 1e3, "launches": n_launch,
+                         "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n, "prims_per_segment": v_p,
+                         "trace_fraction_of_step": trace_s / dt, "shade_fraction_of_step": shade_s / dt,
+                         "trace_rays_per_s": seg0 / trace_s, "trace_rays_per_s_bounces_only": bounce_rays_per_s,
+                         "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak" % (info["device_bytes"] / 2 ** 20)},
+            "scene": {"bvh_nodes": info["n_nodes"], "bvh_depth": info["bvh_depth"], "device_mb": info["device_bytes"] / 2 ** 20,
+                      "bvh_build_s": info["build_seconds"], "upload_s": info["upload_seconds"], "create_s": create_s},
+            "image_mean": float(img.mean()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, cam, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

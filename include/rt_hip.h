@@ -136,6 +136,9 @@ typedef struct rt_stats {
     double seconds_shade;    /* device time in raygen + shade + accumulate              */
     double seconds_total;    /* device time first launch -> last launch                 */
     uint64_t trace_launches; /* number of trace-kernel launches timed in seconds_trace  */
+    uint64_t primary_segments;     /* camera rays (depth 0) among ray_segments                 */
+    double seconds_trace_primary;  /* part of seconds_trace spent on depth-0 launches; the
+                                      rest is the incoherent-bounce part                      */
 } rt_stats;
 
 typedef struct rt_ray { double o[3], d[3]; } rt_ray;   /* d need not be normalised: Ray::new does */

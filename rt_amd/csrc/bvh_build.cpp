@@ -1,0 +1,242 @@
+// bvh_build.cpp — binned-SAH BVH2 builder (host).  See bvh_build.h.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace rt {
+namespace {
+
+constexpr int NBINS = 16;
+constexpr double COST_TRAVERSE = 1.0;
+constexpr double COST_PRIM = 1.0;
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+struct Box {
+    double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+    void grow(const double* l, const double* h) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], l[k]);
+            hi[k] = std::max(hi[k], h[k]);
+        }
+    }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    void grow_point(const double* p) { grow(p, p); }
+    double half_area() const {
+        double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        return ex * ey + ey * ez + ez * ex;
+    }
+};
+
+inline int ceil_log2(size_t n) {
+    int l = 0;
+    while ((size_t(1) << l) < n) ++l;
+    return l;
+}
+
+struct Builder {
+    const std::vector<PrimBox>& pb;
+    size_t nsph;
+    std::vector<uint32_t> idx;
+    std::vector<double> cent;   // 3 per prim
+    BvhResult& out;
+
+    Builder(const std::vector<PrimBox>& b, size_t ns, BvhResult& o) : pb(b), nsph(ns), out(o) {
+        idx.resize(b.size());
+        cent.resize(3 * b.size());
+        for (size_t i = 0; i < b.size(); ++i) {
+            idx[i] = (uint32_t)i;
+            for (int k = 0; k < 3; ++k) cent[3 * i + k] = 0.5 * (b[i].lo[k] + b[i].hi[k]);
+        }
+    }
+
+    bool homogeneous(size_t first, size_t count) const {
+        bool s0 = idx[first] < nsph;
+        for (size_t i = first + 1; i < first + count; ++i)
+            if ((idx[i] < nsph) != s0) return false;
+        return true;
+    }
+
+    uint32_t make_leaf(size_t first, size_t count, int depth) {
+        bool sph = idx[first] < nsph;
+        uint32_t start;
+        if (sph) {
+            start = (uint32_t)out.sph_order.size();
+            for (size_t i = first; i < first + count; ++i) out.sph_order.push_back(idx[i]);
+        } else {
+            start = (uint32_t)out.tri_order.size();
+            for (size_t i = first; i < first + count; ++i) out.tri_order.push_back(idx[i] - (uint32_t)nsph);
+        }
+        out.depth = std::max(out.depth, (uint32_t)depth);
+        out.max_leaf = std::max(out.max_leaf, (uint32_t)count);
+        return REF_LEAF | (sph ? REF_SPHERE : 0u) | ((uint32_t)(count - 1) << 28) | start;
+    }
+
+    // Builds the subtree over idx[first, first+count); returns its child reference (which sits at
+    // `depth`) and its bounds.  Invariant: ceil_log2(count) <= BVH_MAX_DEPTH - depth.
+    uint32_t build(size_t first, size_t count, int depth, Box& bounds) {
+        Box cb;
+        bounds = Box();
+        for (size_t i = first; i < first + count; ++i) {
+            const PrimBox& p = pb[idx[i]];
+            bounds.grow(p.lo, p.hi);
+            cb.grow_point(&cent[3 * idx[i]]);
+        }
+        const bool can_leaf = count <= (size_t)MAX_LEAF && homogeneous(first, count);
+        if (count == 1) return make_leaf(first, count, depth);
+
+        // --- binned SAH over the three axes
+        double best_cost = INF;
+        int best_axis = -1, best_split = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            double c0 = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0.0)) continue;
+            size_t cnt[NBINS] = {0};
+            Box bb[NBINS];
+            double scale = NBINS / ext;
+            for (size_t i = first; i < first + count; ++i) {
+                int k = (int)((cent[3 * idx[i] + ax] - c0) * scale);
+                k = std::min(std::max(k, 0), NBINS - 1);
+                cnt[k]++;
+                bb[k].grow(pb[idx[i]].lo, pb[idx[i]].hi);
+            }
+            double right_area[NBINS];
+            size_t right_cnt[NBINS];
+            Box acc;
+            size_t c = 0;
+            for (int k = NBINS - 1; k >= 1; --k) {
+                if (cnt[k]) acc.grow(bb[k]);
+                c += cnt[k];
+                right_area[k] = c ? acc.half_area() : 0.0;
+                right_cnt[k] = c;
+            }
+            acc = Box();
+            c = 0;
+            for (int s = 1; s < NBINS; ++s) {
+                if (cnt[s - 1]) acc.grow(bb[s - 1]);
+                c += cnt[s - 1];
+                if (!c || !right_cnt[s]) continue;
+                double cost = acc.half_area() * (double)c + right_area[s] * (double)right_cnt[s];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = s; }
+            }
+        }
+        const double area = bounds.half_area();
+        if (can_leaf) {
+            double split_cost = best_axis >= 0 && area > 0.0 ? COST_TRAVERSE + COST_PRIM * best_cost / area : INF;
+            if ((double)count * COST_PRIM <= split_cost) return make_leaf(first, count, depth);
+        }
+
+        // --- partition
+        const int remaining = BVH_MAX_DEPTH - depth;   // levels available below this reference
+        size_t mid = first;
+        if (best_axis >= 0) {
+            double c0 = cb.lo[best_axis], scale = NBINS / (cb.hi[best_axis] - cb.lo[best_axis]);
+            auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t p) {
+                int k = (int)((cent[3 * p + best_axis] - c0) * scale);
+                k = std::min(std::max(k, 0), NBINS - 1);
+                return k < best_split;
+            });
+            mid = (size_t)(it - idx.begin());
+        }
+        size_t nl = mid - first, nr = count - nl;
+        if (nl == 0 || nr == 0 || ceil_log2(nl) > remaining - 1 || ceil_log2(nr) > remaining - 1) {
+            // spatial median along the widest centroid axis: keeps the depth invariant
+            int ax = 0;
+            for (int k = 1; k < 3; ++k)
+                if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+            mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return cent[3 * a + ax] < cent[3 * b + ax]; });
+            nl = mid - first;
+            nr = count - nl;
+        }
+
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Box bl, br;
+        uint32_t l = build(first, nl, depth + 1, bl);
+        uint32_t r = build(mid, nr, depth + 1, br);
+        Node64& n = out.nodes[me];
+        for (int k = 0; k < 3; ++k) {
+            n.lo_l[k] = bl.lo[k]; n.hi_l[k] = bl.hi[k];
+            n.lo_r[k] = br.lo[k]; n.hi_r[k] = br.hi[k];
+        }
+        n.left = l;
+        n.right = r;
+        for (uint32_t& p : n._pad) p = 0;
+        out.depth = std::max(out.depth, (uint32_t)depth + 1);
+        return me;
+    }
+};
+
+inline float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+}  // namespace
+
+void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out) {
+    out = BvhResult();
+    const size_t n = boxes.size();
+    if (n == 0) return;
+    out.nodes.reserve(n / 2 + 16);
+    out.tri_order.reserve(n - n_spheres);
+    out.sph_order.reserve(n_spheres);
+    Builder B(boxes, n_spheres, out);
+    Box bounds;
+    // Probe: would the whole scene be a single leaf?  Then wrap it so that node 0 always exists.
+    bool single = n == 1 || (n <= (size_t)MAX_LEAF && B.homogeneous(0, n));
+    if (single) {
+        Box b;
+        for (size_t i = 0; i < n; ++i) b.grow(boxes[i].lo, boxes[i].hi);
+        out.nodes.emplace_back();
+        uint32_t leaf = B.make_leaf(0, n, 1);
+        Node64& nd = out.nodes[0];
+        for (int k = 0; k < 3; ++k) {
+            nd.lo_l[k] = b.lo[k]; nd.hi_l[k] = b.hi[k];
+            nd.lo_r[k] = INF; nd.hi_r[k] = -INF;
+        }
+        nd.left = leaf;
+        nd.right = REF_EMPTY;
+        for (uint32_t& p : nd._pad) p = 0;
+        return;
+    }
+    uint32_t root = B.build(0, n, 0, bounds);
+    if (root & REF_LEAF) {
+        // count in (1, MAX_LEAF] and SAH preferred a leaf: cannot happen (handled by `single`),
+        // kept for safety.
+        out.nodes.emplace_back();
+        Node64& nd = out.nodes[0];
+        for (int k = 0; k < 3; ++k) {
+            nd.lo_l[k] = bounds.lo[k]; nd.hi_l[k] = bounds.hi[k];
+            nd.lo_r[k] = INF; nd.hi_r[k] = -INF;
+        }
+        nd.left = root;
+        nd.right = REF_EMPTY;
+    }
+}
+
+void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out) {
+    out.resize(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+        const Node64& a = in[i];
+        Node32& b = out[i];
+        for (int k = 0; k < 3; ++k) {
+            b.lo_l[k] = round_down(a.lo_l[k]); b.hi_l[k] = round_up(a.hi_l[k]);
+            b.lo_r[k] = round_down(a.lo_r[k]); b.hi_r[k] = round_up(a.hi_r[k]);
+        }
+        b.left = a.left;
+        b.right = a.right;
+        b._pad[0] = b._pad[1] = 0;
+    }
+}
+
+}  // namespace rt

@@ -1,0 +1,30 @@
+// bvh_build.h — host BVH builder for the flattened scene (replaces bvh::Bvh::build_par, which the
+// reference calls at src/hittable.rs:34).  Binned SAH, BVH2 with child boxes in the parent,
+// homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= BVH_MAX_DEPTH.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "rt_layout.h"
+
+namespace rt {
+
+struct PrimBox {
+    double lo[3], hi[3];
+};
+
+struct BvhResult {
+    std::vector<Node64> nodes;          // nodes[0] is the root when n_prims > 0
+    std::vector<uint32_t> tri_order;    // leaf order -> index into the input triangle array
+    std::vector<uint32_t> sph_order;    // leaf order -> index into the input sphere array
+    uint32_t depth = 0;                 // deepest child reference
+    uint32_t max_leaf = 0;
+};
+
+// boxes: first n_spheres entries are spheres, the rest triangles (the caller's primitive order).
+void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out);
+
+// f32 copy of the nodes with boxes rounded outward.
+void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out);
+
+}  // namespace rt

@@ -1,0 +1,668 @@
+// rt_api.hip — the C ABI of librt_hip.so (include/rt_hip.h): scene flattening + upload, and the
+// host side of the wavefront loop.  No CPU render path exists here: every compute entry point
+// needs a HIP device and fails with RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "rt_kernels.h"
+#include "rt_layout.h"
+
+static_assert(sizeof(rt_sphere) == 64 && sizeof(rt_triangle) == 152 && sizeof(rt_material) == 32 &&
+                  sizeof(rt_texture) == 64 && sizeof(rt_sky) == 144 && sizeof(rt_camera) == 184 &&
+                  sizeof(rt_opts) == 40 && sizeof(rt_stats) == 88 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
+                  sizeof(rt_scene_info) == 64,
+              "ABI struct sizes (mirrored in rt_amd/_abi.py)");
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (void)hipGetLastError();                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorName(e_), __FILE__, __LINE__);                                \
+        }                                                                                        \
+    } while (0)
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_device_mu[MAX_DEVICES];
+
+int select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_NO_DEVICE, "no HIP device available (%s); librt_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorName(e));
+    }
+    if (device < 0 || device >= n || device >= MAX_DEVICES)
+        return fail(RT_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    return RT_OK;
+}
+
+// frees a list of device allocations unless released
+struct DevAllocs {
+    std::vector<void*> ptrs;
+    ~DevAllocs() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    int alloc(T** out, size_t count) {
+        void* p = nullptr;
+        size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorName(e));
+        }
+        ptrs.push_back(p);
+        *out = (T*)p;
+        return RT_OK;
+    }
+};
+
+struct Workspace {
+    size_t capacity = 0;          // paths
+    char* base = nullptr;         // one device allocation, carved below
+    size_t bytes = 0;
+    RayQueue q[2];
+    HitBuf hb;
+    double* path_radiance = nullptr;
+    uint32_t* counters = nullptr;             // 2 counters, 256 B apart
+    unsigned long long* stat_counters = nullptr;   // [2], own 256-B block
+    uint32_t* h_count = nullptr;              // pinned
+    unsigned long long* h_stat = nullptr;     // pinned [2]
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    DScene d{};
+    std::vector<void*> allocs;
+    rt_scene_info info{};
+    std::mutex mu;
+    Workspace ws;
+};
+
+namespace {
+
+void free_workspace(Workspace& w) {
+    if (w.base) (void)hipFree(w.base);
+    if (w.h_count) (void)hipHostFree(w.h_count);
+    if (w.h_stat) (void)hipHostFree(w.h_stat);
+    for (auto& e : w.ev)
+        if (e) (void)hipEventDestroy(e);
+    w = Workspace();
+}
+
+int ensure_workspace(rt_scene* sc, size_t paths) {
+    Workspace& w = sc->ws;
+    if (!w.h_count) {
+        HIPCHK(hipHostMalloc((void**)&w.h_count, 256, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&w.h_stat, 256, hipHostMallocDefault));
+        for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
+    }
+    if (paths <= w.capacity) return RT_OK;
+    if (w.base) {
+        (void)hipFree(w.base);
+        w.base = nullptr;
+        w.capacity = 0;
+    }
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t dsz = up(paths * sizeof(double)), usz = up(paths * sizeof(uint32_t));
+    size_t total = 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 3 * 256;
+    char* p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, total);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) for %zu paths in flight failed: %s", total, paths, hipGetErrorName(e));
+    }
+    w.base = p;
+    w.bytes = total;
+    auto take = [&](size_t n) { char* r = p; p += n; return r; };
+    for (int k = 0; k < 2; ++k) {
+        for (int c = 0; c < 3; ++c) w.q[k].o[c] = (double*)take(dsz);
+        for (int c = 0; c < 3; ++c) w.q[k].d[c] = (double*)take(dsz);
+        for (int c = 0; c < 3; ++c) w.q[k].thr[c] = (double*)take(dsz);
+        w.q[k].pid = (uint32_t*)take(usz);
+    }
+    w.hb.t = (double*)take(dsz);
+    w.hb.bu = (double*)take(dsz);
+    w.hb.bv = (double*)take(dsz);
+    w.hb.prim = (uint32_t*)take(usz);
+    w.path_radiance = (double*)take(up(3 * paths * sizeof(double)));
+    w.counters = (uint32_t*)take(512);
+    w.stat_counters = (unsigned long long*)take(256);
+    w.capacity = paths;
+    return RT_OK;
+}
+
+// Rotation3::from_euler_angles(roll, pitch, yaw) = Rz(yaw) * Ry(pitch) * Rx(roll)
+void euler_matrix(double roll, double pitch, double yaw, double m[9]) {
+    const double sr = std::sin(roll), cr = std::cos(roll);
+    const double sp = std::sin(pitch), cp = std::cos(pitch);
+    const double sy = std::sin(yaw), cy = std::cos(yaw);
+    m[0] = cy * cp; m[1] = cy * sp * sr - sy * cr; m[2] = cy * sp * cr + sy * sr;
+    m[3] = sy * cp; m[4] = sy * sp * sr + cy * cr; m[5] = sy * sp * cr - cy * sr;
+    m[6] = -sp;     m[7] = cp * sr;                m[8] = cp * cr;
+}
+// unit_sphere_uv_facing (src/hittable.rs:392-400) + the matrix product of unit_sphere_uv (:376-377)
+void sphere_texture_rotation(const double f[3], double r[9]) {
+    const double pitch = std::atan2(f[2], std::sqrt(f[1] * f[1] + f[0] * f[0]));
+    const double yaw = std::atan2(f[1], f[0]);
+    double a[9], b[9];
+    euler_matrix(0.0, pitch, 0.0, a);
+    euler_matrix(0.0, 0.0, -yaw, b);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+bool finite3(const double* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+template <class T>
+int upload(rt_scene* sc, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorName(e));
+    }
+    sc->allocs.push_back(p);
+    sc->info.device_bytes += bytes;
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return RT_OK;
+}
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int check_camera(const rt_camera* cam) {
+    if (!cam) return fail(RT_ERR_INVALID, "camera is NULL");
+    if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID, "camera has zero size");
+    if ((uint64_t)cam->width * cam->height > (1ull << 31)) return fail(RT_ERR_LIMIT, "image larger than 2^31 pixels");
+    return RT_OK;
+}
+
+constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 25;
+
+// The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
+int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
+                rt_stats* stats) {
+    const uint32_t stride = opts->sample_stride ? opts->sample_stride : 1;
+    if (opts->spp == 0) return fail(RT_ERR_INVALID, "spp must be >= 1");
+    if (opts->precision != 0 && opts->precision != RT_PRECISION_F64)
+        return fail(RT_ERR_INVALID, "precision %u not supported (use RT_PRECISION_F64)", opts->precision);
+    const uint64_t last = (uint64_t)opts->sample_offset + (uint64_t)(opts->spp - 1) * stride;
+    if (last >= RT_MAX_SAMPLE_INDEX)
+        return fail(RT_ERR_LIMIT, "sample index %llu exceeds the Halton table limit %u (src/camera.rs:208-210)",
+                    (unsigned long long)last, RT_MAX_SAMPLE_INDEX);
+    const size_t npix = (size_t)cam->width * cam->height;
+    const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
+    const uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
+    if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
+    int rc = ensure_workspace(sc, npix * per_pass);
+    if (rc) return rc;
+    Workspace& w = sc->ws;
+
+    PassParams pp;
+    pp.cam = *cam;
+    pp.seed = opts->seed;
+    pp.n_pixels = (uint32_t)npix;
+    pp.sample_offset = opts->sample_offset;
+    pp.sample_stride = stride;
+    pp.jitter = 1;
+
+    rt_stats st;
+    memset(&st, 0, sizeof(st));
+    const bool want_stats = opts->collect_stats != 0;
+    if (want_stats) HIPCHK(hipMemsetAsync(w.stat_counters, 0, 256, stream));
+    const double t0 = now_s();
+    for (uint32_t base = 0; base < opts->spp; base += per_pass) {
+        const uint32_t nl = std::min(per_pass, opts->spp - base);
+        uint32_t n = (uint32_t)(npix * nl);
+        pp.pass_base = base;
+        HIPCHK(hipEventRecord(w.ev[0], stream));
+        launch_raygen(pp, n, w.q[0], stream);
+        HIPCHK(hipEventRecord(w.ev[1], stream));
+        st.launches++;
+        int cur = 0;
+        for (uint32_t depth = 0; depth <= cam->max_depth && n > 0; ++depth) {
+            // the survivors' counter: its own 256-byte block, zeroed on the stream before every use
+            uint32_t* d_count = w.counters + 64 * (depth & 1u);
+            HIPCHK(hipMemsetAsync(d_count, 0, 256, stream));
+            HIPCHK(hipEventRecord(w.ev[2], stream));
+            launch_trace(sc->d, w.q[cur], n, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
+            HIPCHK(hipEventRecord(w.ev[3], stream));
+            launch_shade(sc->d, pp, depth, w.q[cur], n, w.hb, w.q[cur ^ 1], d_count, w.path_radiance, stream);
+            HIPCHK(hipMemcpyAsync(w.h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipEventRecord(w.ev[4], stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipGetLastError());
+            float ms_t = 0.f, ms_s = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms_t, w.ev[2], w.ev[3]));
+            HIPCHK(hipEventElapsedTime(&ms_s, w.ev[3], w.ev[4]));
+            if (depth == 0) {
+                float ms_r = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms_r, w.ev[0], w.ev[1]));
+                st.seconds_shade += ms_r * 1e-3;
+            }
+            st.seconds_trace += ms_t * 1e-3;
+            st.seconds_shade += ms_s * 1e-3;
+            if (depth == 0) {
+                st.seconds_trace_primary += ms_t * 1e-3;
+                st.primary_segments += n;
+            }
+            st.trace_launches++;
+            st.launches += 2;
+            st.ray_segments += n;
+            n = *w.h_count;
+            cur ^= 1;
+        }
+        HIPCHK(hipEventRecord(w.ev[0], stream));
+        launch_accumulate(w.path_radiance, (uint32_t)npix, nl, d_rgb_sum, stream);
+        HIPCHK(hipEventRecord(w.ev[1], stream));
+        HIPCHK(hipEventSynchronize(w.ev[1]));
+        float ms_a = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms_a, w.ev[0], w.ev[1]));
+        st.seconds_shade += ms_a * 1e-3;
+        st.launches++;
+        st.passes++;
+        st.samples += (uint64_t)npix * nl;
+    }
+    if (want_stats) HIPCHK(hipMemcpyAsync(w.h_stat, w.stat_counters, 16, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    st.seconds_total = now_s() - t0;
+    if (want_stats) {
+        st.nodes_visited = w.h_stat[0];
+        st.prims_tested = w.h_stat[1];
+    }
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(int* count) {
+    if (!count) return fail(RT_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorName(e));
+    }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangle* triangles, size_t n_triangles,
+                    const rt_material* materials, size_t n_materials, const rt_texture* textures, size_t n_textures,
+                    const uint8_t* texel_pool, size_t texel_pool_bytes, const rt_sky* sky, int device, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!sky) return fail(RT_ERR_INVALID, "sky is NULL");
+    if ((n_spheres && !spheres) || (n_triangles && !triangles) || (n_materials && !materials) ||
+        (n_textures && !textures) || (texel_pool_bytes && !texel_pool))
+        return fail(RT_ERR_INVALID, "NULL array with non-zero count");
+    const size_t n_prims = n_spheres + n_triangles;
+    if (n_prims >= REF_FIRST_MASK) return fail(RT_ERR_LIMIT, "more than 2^28-1 primitives");
+    // ---- validate references (a bad index would be an out-of-bounds read on the GPU)
+    for (size_t i = 0; i < n_textures; ++i) {
+        const rt_texture& t = textures[i];
+        if (t.kind > RT_TEX_IMAGE) return fail(RT_ERR_INVALID, "texture %zu: bad kind %u", i, t.kind);
+        if (t.kind == RT_TEX_CHECKER && (t.even >= i || t.odd >= i))
+            return fail(RT_ERR_INVALID, "texture %zu: checker children must precede it", i);
+        if (t.kind == RT_TEX_IMAGE) {
+            if (t.texel_format > RT_TEXEL_RGBA16) return fail(RT_ERR_INVALID, "texture %zu: bad texel format", i);
+            const size_t bpt = t.texel_format == RT_TEXEL_RGBA16 ? 8 : 4;
+            if (!t.width || !t.height || (t.texel_offset % bpt) != 0 ||
+                t.texel_offset + (size_t)t.width * t.height * bpt > texel_pool_bytes)
+                return fail(RT_ERR_INVALID, "texture %zu: image outside the texel pool", i);
+        }
+    }
+    for (size_t i = 0; i < n_materials; ++i) {
+        const rt_material& m = materials[i];
+        if (m.kind > RT_MAT_DIELECTRIC) return fail(RT_ERR_INVALID, "material %zu: bad kind %u", i, m.kind);
+        if (m.kind != RT_MAT_DIELECTRIC && m.texture >= n_textures)
+            return fail(RT_ERR_INVALID, "material %zu: texture %u out of range", i, m.texture);
+    }
+    for (size_t i = 0; i < n_spheres; ++i) {
+        if (spheres[i].material >= n_materials) return fail(RT_ERR_INVALID, "sphere %zu: material out of range", i);
+        if (!finite3(spheres[i].center) || !std::isfinite(spheres[i].radius) || spheres[i].radius < 0.0)
+            return fail(RT_ERR_INVALID, "sphere %zu: non-finite or negative geometry", i);
+    }
+    for (size_t i = 0; i < n_triangles; ++i) {
+        if (triangles[i].material >= n_materials) return fail(RT_ERR_INVALID, "triangle %zu: material out of range", i);
+        if (!finite3(triangles[i].a) || !finite3(triangles[i].b) || !finite3(triangles[i].c))
+            return fail(RT_ERR_INVALID, "triangle %zu: non-finite vertex", i);
+    }
+    int rc = select_device(device);
+    if (rc) return rc;
+
+    rt_scene* sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_OOM, "out of host memory");
+    sc->device = device;
+    struct Guard {
+        rt_scene* s;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard{sc};
+
+    try {
+        // ---- bounds (Bounded::aabb: src/hittable.rs:242-248, :299-306) and BVH
+        const double tb0 = now_s();
+        std::vector<PrimBox> boxes(n_prims);
+        for (size_t i = 0; i < n_spheres; ++i)
+            for (int k = 0; k < 3; ++k) {
+                boxes[i].lo[k] = spheres[i].center[k] - spheres[i].radius;
+                boxes[i].hi[k] = spheres[i].center[k] + spheres[i].radius;
+            }
+        for (size_t i = 0; i < n_triangles; ++i) {
+            const rt_triangle& t = triangles[i];
+            for (int k = 0; k < 3; ++k) {
+                boxes[n_spheres + i].lo[k] = std::min(std::min(t.a[k], t.b[k]), t.c[k]);
+                boxes[n_spheres + i].hi[k] = std::max(std::max(t.a[k], t.b[k]), t.c[k]);
+            }
+        }
+        BvhResult bvh;
+        build_bvh(boxes, n_spheres, bvh);
+        if (bvh.depth > (uint32_t)BVH_MAX_DEPTH)
+            return fail(RT_ERR_LIMIT, "internal: BVH depth %u exceeds the traversal stack (%d)", bvh.depth, BVH_MAX_DEPTH);
+        if (bvh.tri_order.size() != n_triangles || bvh.sph_order.size() != n_spheres)
+            return fail(RT_ERR_INVALID, "internal: BVH lost primitives");
+        boxes.clear();
+        boxes.shrink_to_fit();
+
+        // ---- flatten
+        std::vector<TriGeom> tg(n_triangles);
+        for (size_t k = 0; k < n_triangles; ++k) {
+            const rt_triangle& t = triangles[bvh.tri_order[k]];
+            for (int c = 0; c < 3; ++c) {
+                tg[k].a[c] = t.a[c];
+                tg[k].e1[c] = t.b[c] - t.a[c];           // a_to_b (src/hittable.rs:412)
+                tg[k].e2[c] = t.c[c] - t.a[c];           // a_to_c (:413)
+            }
+            tg[k].prim = (uint32_t)(n_spheres + bvh.tri_order[k]);
+            tg[k]._pad = 0;
+        }
+        std::vector<TriShade> tsh(n_triangles);
+        for (size_t i = 0; i < n_triangles; ++i) {
+            const rt_triangle& t = triangles[i];
+            for (int c = 0; c < 3; ++c) tsh[i].n[c] = t.n[c];
+            // f64::min/max chain (src/hittable.rs:469-476)
+            const double left = std::fmin(std::fmin(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
+            const double right = std::fmax(std::fmax(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
+            const double bot = std::fmin(std::fmin(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
+            const double top = std::fmax(std::fmax(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
+            tsh[i].uv_left = left; tsh[i].uv_width = right - left;
+            tsh[i].uv_bot = bot; tsh[i].uv_height = top - bot;
+            tsh[i].material = t.material;
+            tsh[i]._pad = 0;
+        }
+        std::vector<SphShade> ssh(n_spheres);
+        for (size_t i = 0; i < n_spheres; ++i) {
+            const rt_sphere& s = spheres[i];
+            for (int c = 0; c < 3; ++c) ssh[i].c[c] = s.center[c];
+            ssh[i].r = s.radius;
+            sphere_texture_rotation(s.face, ssh[i].rot);
+            ssh[i].material = s.material;
+            ssh[i]._pad = 0;
+        }
+        std::vector<SphGeom> sg(n_spheres);
+        for (size_t k = 0; k < n_spheres; ++k) {
+            const uint32_t i = bvh.sph_order[k];
+            for (int c = 0; c < 3; ++c) {
+                sg[k].c[c] = spheres[i].center[c];
+                sg[k].rot2[c] = ssh[i].rot[6 + c];
+            }
+            sg[k].r = spheres[i].radius;
+            sg[k].prim = i;
+            sg[k]._pad = 0;
+        }
+        const double tb1 = now_s();
+
+        // ---- upload
+        std::vector<rt_material> mats(materials, materials + n_materials);
+        std::vector<rt_texture> texs(textures, textures + n_textures);
+        std::vector<uint8_t> pool(texel_pool, texel_pool + texel_pool_bytes);
+        if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
+        if ((rc = upload(sc, tg, &sc->d.tris))) return rc;
+        if ((rc = upload(sc, sg, &sc->d.sphs))) return rc;
+        if ((rc = upload(sc, tsh, &sc->d.tri_shade))) return rc;
+        if ((rc = upload(sc, ssh, &sc->d.sph_shade))) return rc;
+        if ((rc = upload(sc, mats, &sc->d.mats))) return rc;
+        if ((rc = upload(sc, texs, &sc->d.texs))) return rc;
+        if ((rc = upload(sc, pool, &sc->d.texels))) return rc;
+        sc->d.nodes32 = nullptr;
+        sc->d.n_spheres = (uint32_t)n_spheres;
+        sc->d.n_prims = (uint32_t)n_prims;
+        sc->d.root = n_prims ? 0u : REF_EMPTY;
+        sc->d.sky = *sky;
+        HIPCHK(hipDeviceSynchronize());
+        const double tb2 = now_s();
+
+        sc->info.n_prims = n_prims;
+        sc->info.n_nodes = bvh.nodes.size();
+        sc->info.bvh_depth = bvh.depth;
+        sc->info.max_leaf_size = bvh.max_leaf;
+        sc->info.node_bytes = sizeof(Node64);
+        sc->info.tri_bytes = sizeof(TriGeom);
+        sc->info.sphere_bytes = sizeof(SphGeom);
+        sc->info.build_seconds = tb1 - tb0;
+        sc->info.upload_seconds = tb2 - tb1;
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_OOM, "out of host memory while flattening the scene");
+    }
+    guard.s = nullptr;
+    *out = sc;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return;
+    if (hipSetDevice(sc->device) == hipSuccess) {
+        free_workspace(sc->ws);
+        for (void* p : sc->allocs) (void)hipFree(p);
+    }
+    (void)hipGetLastError();
+    delete sc;
+}
+
+int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
+    if (!sc || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = sc->info;
+    return RT_OK;
+}
+
+int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t_min, double t_max, rt_hit* out,
+                     rt_stats* stats) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (n && (!rays || !out)) return fail(RT_ERR_INVALID, "rays/out is NULL");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!n) return RT_OK;
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    int rc = select_device(sc->device);
+    if (rc) return rc;
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
+    if ((rc = ensure_workspace(sc, chunk))) return rc;
+    Workspace& w = sc->ws;
+    DevAllocs tmp;
+    rt_ray* d_rays = nullptr;
+    rt_hit* d_hits = nullptr;
+    if ((rc = tmp.alloc(&d_rays, chunk))) return rc;
+    if ((rc = tmp.alloc(&d_hits, chunk))) return rc;
+    hipStream_t stream = nullptr;
+    const bool want_stats = stats != nullptr;
+    if (want_stats) HIPCHK(hipMemsetAsync(w.stat_counters, 0, 256, stream));
+    const double t0 = now_s();
+    for (size_t off = 0; off < n; off += chunk) {
+        const uint32_t m = (uint32_t)std::min(chunk, n - off);
+        HIPCHK(hipMemcpyAsync(d_rays, rays + off, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
+        launch_prepare_rays(d_rays, m, w.q[0], stream);
+        HIPCHK(hipEventRecord(w.ev[0], stream));
+        launch_trace(sc->d, w.q[0], m, t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
+        HIPCHK(hipEventRecord(w.ev[1], stream));
+        launch_pack_hits(w.hb, m, d_hits, stream);
+        HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipGetLastError());
+        if (stats) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+            stats->seconds_trace += ms * 1e-3;
+            stats->trace_launches++;
+            stats->launches += 3;
+        }
+    }
+    if (stats) {
+        HIPCHK(hipMemcpy(w.h_stat, w.stat_counters, 16, hipMemcpyDeviceToHost));
+        stats->ray_segments = n;
+        stats->nodes_visited = w.h_stat[0];
+        stats->prims_tested = w.h_stat[1];
+        stats->seconds_total = now_s() - t0;
+    }
+    return RT_OK;
+}
+
+int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_index, int jitter, uint64_t seed,
+                     rt_hit* out, rt_ray* rays_out) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (sample_index >= RT_MAX_SAMPLE_INDEX) return fail(RT_ERR_LIMIT, "sample index beyond the Halton table");
+    const size_t npix = (size_t)cam->width * cam->height;
+    if (npix > DEFAULT_PATHS_IN_FLIGHT) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^25 pixels");
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    if ((rc = select_device(sc->device))) return rc;
+    if ((rc = ensure_workspace(sc, npix))) return rc;
+    Workspace& w = sc->ws;
+    DevAllocs tmp;
+    rt_hit* d_hits = nullptr;
+    rt_ray* d_rays = nullptr;
+    if ((rc = tmp.alloc(&d_hits, npix))) return rc;
+    if (rays_out && (rc = tmp.alloc(&d_rays, npix))) return rc;
+    PassParams pp;
+    pp.cam = *cam;
+    pp.seed = seed;
+    pp.n_pixels = (uint32_t)npix;
+    pp.sample_offset = sample_index;
+    pp.sample_stride = 1;
+    pp.pass_base = 0;
+    pp.jitter = jitter ? 1 : 0;
+    hipStream_t stream = nullptr;
+    launch_raygen(pp, (uint32_t)npix, w.q[0], stream);
+    launch_trace(sc->d, w.q[0], (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
+    launch_pack_hits(w.hb, (uint32_t)npix, d_hits, stream);
+    HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
+    if (rays_out) {
+        launch_pack_rays(w.q[0], (uint32_t)npix, d_rays, stream);
+        HIPCHK(hipMemcpyAsync(rays_out, d_rays, npix * sizeof(rt_ray), hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_accumulate_device(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum,
+                                void* stream, rt_stats* stats) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc || !opts || !d_rgb_sum) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (opts->device != sc->device)
+        return fail(RT_ERR_INVALID, "opts.device (%d) differs from the scene's device (%d)", opts->device, sc->device);
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    if ((rc = select_device(sc->device))) return rc;
+    return render_into(sc, cam, opts, d_rgb_sum, (hipStream_t)stream, stats);
+}
+
+int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_values, uint64_t total_spp, int device,
+                      void* stream) {
+    if (!d_rgb_sum || !d_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!total_spp) return fail(RT_ERR_INVALID, "total_spp must be >= 1");
+    int rc = select_device(device);
+    if (rc) return rc;
+    launch_resolve(d_rgb_sum, d_rgb_mean, n_values, (double)total_spp, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, double* out_rgb_mean, rt_stats* stats) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc || !opts || !out_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (opts->device != sc->device)
+        return fail(RT_ERR_INVALID, "opts.device (%d) differs from the scene's device (%d)", opts->device, sc->device);
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    if ((rc = select_device(sc->device))) return rc;
+    const size_t nval = (size_t)cam->width * cam->height * 3;
+    DevAllocs tmp;
+    double* d_sum = nullptr;
+    if ((rc = tmp.alloc(&d_sum, nval))) return rc;
+    hipStream_t stream = nullptr;
+    HIPCHK(hipMemsetAsync(d_sum, 0, nval * sizeof(double), stream));
+    if ((rc = render_into(sc, cam, opts, d_sum, stream, stats))) return rc;
+    launch_resolve(d_sum, d_sum, nval, (double)opts->spp, stream);
+    HIPCHK(hipMemcpyAsync(out_rgb_mean, d_sum, nval * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_encode_gamma8(const double* rgb_mean, size_t n_values, uint8_t* out) {
+    if (n_values && (!rgb_mean || !out)) return fail(RT_ERR_INVALID, "NULL argument");
+    const double gamma = 1.0 / 2.2;                      // as_gamma_vec (src/vec3.rs:39-42)
+    for (size_t i = 0; i < n_values; ++i) {
+        double c = rgb_mean[i];
+        if (!(c >= 0.0)) c = 0.0;                        // the reference panics outside [0,1] (:71-90); clamp instead
+        if (c > 1.0) c = 1.0;
+        out[i] = (uint8_t)std::round(std::pow(c, gamma) * 255.0);
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// rt_device.h — device-side f64 arithmetic of the render hot path (gfx950).
+//
+// Every routine cites the reference lines whose arithmetic it reproduces; operation order follows
+// nalgebra 0.33 as recalled in SURVEY.md App. B (dot = (x0*y0 + x1*y1) + x2*y2, normalize = v / |v|).
+// The translation unit is compiled with -ffp-contract=off: Rust never fuses a*b+c, and the
+// closest-hit (prim, t) contract is bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_layout.h"
+
+namespace rt {
+
+struct D3 { double x, y, z; };
+
+__device__ __forceinline__ D3 mk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ D3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ D3 add(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 sub(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 mul(D3 a, D3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ D3 scale(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ D3 divs(D3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ double norm2(D3 a) { return dot(a, a); }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ D3 normalize(D3 a) { return divs(a, sqrt(norm2(a))); }
+
+constexpr double F64_EPSILON = 2.220446049250313e-16;
+constexpr uint32_t DEPTH_PRIMARY = 0xFFFFFFFFu;
+
+// ---- Philox4x32-10 counter RNG ---------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+__device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
+    uint64_t bits = ((uint64_t)hi << 32) | lo;
+    return (double)(bits >> 11) * 0x1.0p-53;
+}
+struct RngKey { uint64_t seed; uint32_t pixel, sample, depth; };
+// block b holds slots 2b (words x,y) and 2b+1 (words z,w)
+__device__ __forceinline__ U4 rng_block(const RngKey& k, uint32_t block) {
+    return philox4x32_10(k.pixel, k.sample, k.depth, block, (uint32_t)k.seed, (uint32_t)(k.seed >> 32));
+}
+
+// ---- Halton (src/camera.rs:140-165): element `index` = radical inverse of index+1, exact n/d ----
+__device__ __forceinline__ double halton2(uint32_t index) {
+    uint32_t i = index + 1;                       // <= 2^20
+    int bits = 32 - __clz(i);
+    uint32_t n = __brev(i) >> (32 - bits);
+    return (double)n / (double)(1u << bits);
+}
+__device__ __forceinline__ double halton3(uint32_t index) {
+    uint32_t i = index + 1, n = 0, d = 1;         // 3^13 > 2^20, fits in u32
+    while (i) { n = n * 3u + i % 3u; i /= 3u; d *= 3u; }
+    return (double)n / (double)d;
+}
+
+// ---- primitives -----------------------------------------------------------------------------
+// Triangle::hit (src/hittable.rs:408-495) on the precomputed edges; returns true and (dist,u,v).
+__device__ __forceinline__ bool tri_test(D3 a, D3 e1, D3 e2, D3 o, D3 d, double lo, double hi,
+                                         double& dist, double& bu, double& bv) {
+    D3 uvec = cross(d, e2);
+    double det = dot(e1, uvec);
+    if (det < F64_EPSILON) return false;
+    double inv = 1.0 / det;
+    D3 ao = sub(o, a);
+    double u = dot(ao, uvec) * inv;
+    if (!(0.0 <= u && u <= 1.0)) return false;
+    D3 vvec = cross(ao, e1);
+    double v = dot(d, vvec) * inv;
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = dot(e2, vvec) * inv;
+    if (!(lo <= t && t < hi)) return false;
+    if (!(t > F64_EPSILON)) return false;
+    dist = t; bu = u; bv = v;
+    return true;
+}
+
+// Sphere::hit (src/hittable.rs:318-365) up to the NaN-uv rejection, which reduces to
+// !(|z'| <= 1) for the rotated normal's z.
+__device__ __forceinline__ bool sph_test(D3 c, double r, D3 rot2, D3 o, D3 d, double lo, double hi, double& tout) {
+    D3 oc = sub(c, o);
+    double a = norm2(d);
+    double h = dot(d, oc);
+    double cc = norm2(oc) - r * r;
+    double disc = h * h - a * cc;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double t = (h - sq) / a;
+    if (!(lo <= t && t < hi)) {
+        t = (h + sq) / a;
+        if (!(lo <= t && t < hi)) return false;
+    }
+    D3 p = add(scale(d, t), o);
+    D3 n = divs(sub(p, c), r);
+    if (!(dot(d, n) < 0.0)) n = neg(n);
+    double zr = (rot2.x * n.x + rot2.y * n.y) + rot2.z * n.z;
+    if (!(fabs(zr) <= 1.0)) return false;
+    tout = t;
+    return true;
+}
+
+}  // namespace rt
+
+// ---------------------------------------------------------------------------------------------
+// shading-side helpers (used by the shade kernel only)
+// ---------------------------------------------------------------------------------------------
+namespace rt {
+
+constexpr double PI_D = 3.14159265358979323846264338327950288;
+constexpr double TAU_D = 6.28318530717958647692528676655900577;
+
+// Rust `as i32` on f64: saturating, NaN -> 0 (src/texture.rs:63-65)
+__device__ __forceinline__ int32_t f64_as_i32(double x) {
+    if (x != x) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)x;
+}
+__device__ __forceinline__ double clamp01(double x) {   // f64::clamp(0,1); NaN stays NaN
+    if (x < 0.0) return 0.0;
+    if (x > 1.0) return 1.0;
+    return x;
+}
+
+// unit_sphere_uv (src/hittable.rs:370-388) + to_unit_spherical (:402-406) with the per-sphere
+// rotation matrix precomputed at flatten time (unit_sphere_uv_facing, :392-400).
+__device__ __forceinline__ void sphere_uv(D3 n, const double* r, double& u, double& v) {
+    D3 q = mk((r[0] * n.x + r[1] * n.y) + r[2] * n.z,
+              (r[3] * n.x + r[4] * n.y) + r[5] * n.z,
+              (r[6] * n.x + r[7] * n.y) + r[8] * n.z);
+    double theta = acos(-q.z);
+    double phi = atan2(q.y, q.x) + PI_D;
+    phi = phi + 0.0;
+    double m = fmod(phi, TAU_D);
+    if (m < 0.0) m += TAU_D;
+    u = m / TAU_D;
+    v = theta / PI_D;
+}
+
+struct SurfaceHit {
+    D3 p, n;
+    bool front;
+    bool is_sphere;
+    uint32_t material;
+    // uv is evaluated lazily (only image textures read it)
+    double bu, bv;                 // triangle barycentrics
+    const TriShade* ts;
+    const SphShade* ss;
+};
+
+__device__ __forceinline__ void surface_uv(const SurfaceHit& h, double& u, double& v) {
+    if (h.is_sphere) {
+        sphere_uv(h.n, h.ss->rot, u, v);
+    } else {                        // bbox-of-uvs mapping (src/hittable.rs:469-481)
+        u = h.ts->uv_left + h.ts->uv_width * h.bu;
+        v = h.ts->uv_bot + h.ts->uv_height * h.bv;
+    }
+}
+
+// Texture::value for the three kinds (src/texture.rs:25-29, :61-74, :99-118)
+__device__ __forceinline__ D3 texture_value(const DScene& S, uint32_t ti, const SurfaceHit& h) {
+    for (int guard = 0; guard < 64; ++guard) {
+        const rt_texture* t = &S.texs[ti];
+        uint32_t kind = t->kind;
+        if (kind == RT_TEX_SOLID) return ld3(t->rgb);
+        if (kind == RT_TEX_CHECKER) {
+            double is = t->inv_scale;
+            int32_t xi = f64_as_i32(floor(is * h.p.x));
+            int32_t yi = f64_as_i32(floor(is * h.p.y));
+            int32_t zi = f64_as_i32(floor(is * h.p.z));
+            int32_t sum = (int32_t)((uint32_t)xi + (uint32_t)yi + (uint32_t)zi);
+            ti = (sum % 2 == 0) ? t->even : t->odd;
+            continue;
+        }
+        double u, v;
+        surface_uv(h, u, v);
+        double uc = clamp01(u), vc = clamp01(v);
+        uint32_t w = t->width, ht = t->height;
+        double fx = uc * (double)(w - 1), fy = vc * (double)(ht - 1);
+        uint64_t x = (fx != fx || fx <= 0.0) ? 0ull : (uint64_t)fx;     // `as usize`: NaN/negative -> 0
+        uint64_t y = (fy != fy || fy <= 0.0) ? 0ull : (uint64_t)fy;
+        uint64_t texel = y * w + x;
+        if (t->texel_format == RT_TEXEL_RGBA16) {
+            const ushort4 px = *reinterpret_cast<const ushort4*>(S.texels + t->texel_offset + 8 * texel);
+            return mk((double)px.x / 65535.0, (double)px.y / 65535.0, (double)px.z / 65535.0);
+        }
+        const uchar4 px = *reinterpret_cast<const uchar4*>(S.texels + t->texel_offset + 4 * texel);
+        return mk((double)px.x / 255.0, (double)px.y / 255.0, (double)px.z / 255.0);
+    }
+    return mk(0.0, 0.0, 0.0);
+}
+
+// reflect / refract / Schlick (src/material.rs:46-60, :182-186)
+__device__ __forceinline__ D3 reflect(D3 d, D3 n) { return sub(d, scale(scale(n, dot(d, n)), 2.0)); }
+__device__ __forceinline__ D3 refract(D3 d, D3 n, double ratio) {
+    double c = fmin(-dot(d, n), 1.0);
+    D3 perp = scale(add(d, scale(n, c)), ratio);
+    double x = -sqrt(fabs(1.0 - norm2(perp)));
+    return add(scale(n, x), perp);
+}
+__device__ __forceinline__ double reflectance(double cosine, double ri) {
+    double r0 = (1.0 - ri) / (1.0 + ri);
+    r0 = r0 * r0;
+    double a = 1.0 - cosine, a2 = a * a, a4 = a2 * a2;
+    return r0 + (1.0 - r0) * (a * a4);          // powi(5)
+}
+__device__ __forceinline__ bool near_zero(D3 a) {   // src/vec3.rs:105-111
+    const double e = 1.4901161193847656e-08;      // sqrt(f64::EPSILON), exact
+    return fabs(a.x) < e && fabs(a.y) < e && fabs(a.z) < e;
+}
+
+// hw_skymodel::rgb::SkyState::radiance, f32 (recalled)
+__device__ __forceinline__ float sky_radiance(const rt_sky& sky, float theta, float gamma, int ch) {
+    const float* p = &sky.params[9 * ch];
+    float cos_gamma = cosf(gamma);
+    float cos_gamma2 = cos_gamma * cos_gamma;
+    float cos_theta = fabsf(cosf(theta));
+    float exp_m = expf(p[4] * gamma);
+    float ray_m = cos_gamma2;
+    float mie_m_lhs = 1.0f + cos_gamma2;
+    float mie_m_rhs = powf(1.0f + p[8] * p[8] - 2.0f * p[8] * cos_gamma, 1.5f);
+    float mie_m = mie_m_lhs / mie_m_rhs;
+    float zenith = sqrtf(cos_theta);
+    float radiance_lhs = 1.0f + p[0] * expf(p[1] / (cos_theta + 0.01f));
+    float radiance_rhs = p[2] + p[3] * exp_m + p[5] * ray_m + p[6] * mie_m + p[7] * zenith;
+    float radiance_dist = radiance_lhs * radiance_rhs;
+    return sky.radiances[ch] * radiance_dist;
+}
+__device__ __forceinline__ double tonemap1(double x) {   // uncharted2_tonemap (src/hittable.rs:51-66)
+    const double a = 0.15, b = 0.50, c = 0.10, d = 0.20, e = 0.02, f = 0.30;
+    double num = x * (a * x + c * b) + d * e;
+    double den = x * (a * x + b) + d * f;
+    return num / den - e / f;
+}
+// World::sky_color_toward (src/hittable.rs:84-93) + uncharted2 (:70-79)
+__device__ __forceinline__ D3 sky_color_toward(const rt_sky& sky, D3 dir) {
+    float theta = (float)acos(dir.z);
+    double g = dot(dir, ld3(sky.sun));
+    g = g < -1.0 ? -1.0 : (g > 1.0 ? 1.0 : g);
+    float gamma = (float)g;
+    double cr = (double)sky_radiance(sky, theta, gamma, 0);
+    double cg = (double)sky_radiance(sky, theta, gamma, 1);
+    double cb = (double)sky_radiance(sky, theta, gamma, 2);
+    const double exposure_bias = 1.1, w = 11.2;
+    double ws = 1.0 / tonemap1(w);
+    return mk(ws * tonemap1(exposure_bias * cr), ws * tonemap1(exposure_bias * cg), ws * tonemap1(exposure_bias * cb));
+}
+
+}  // namespace rt

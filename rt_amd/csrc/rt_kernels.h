@@ -1,0 +1,39 @@
+// rt_kernels.h — host-callable launchers of the wavefront kernels (rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_layout.h"
+
+namespace rt {
+
+constexpr int BLOCK = 256;
+
+struct PassParams {
+    rt_camera cam;
+    uint64_t seed;
+    uint32_t n_pixels;
+    uint32_t sample_offset, sample_stride;   // global sample = offset + (pass_base + local) * stride
+    uint32_t pass_base;                      // first local sample of this pass
+    uint32_t jitter;                         // 0: debug_ray (pixel centres, pinhole)
+};
+
+// K0: primary rays for path ids [0, n_paths) -> queue
+void launch_raygen(const PassParams& pp, uint32_t n_paths, RayQueue q, hipStream_t s);
+// World::hit input for rt_trace_closest: normalise host rays into a queue (Ray::new)
+void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t s);
+// K1: closest hit for queue[0, n)
+void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb,
+                  bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
+// K2+K3+K4: shade (miss -> sky, hit -> scatter + Russian roulette) and compact survivors into q_out
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
+                  RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s);
+// K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order
+void launch_accumulate(const double* d_path_radiance, uint32_t n_pixels, uint32_t n_local_samples,
+                       double* d_rgb_sum, hipStream_t s);
+// K5b: mean = sum / total_spp
+void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
+// hits (SoA) -> rt_hit[]; slot i holds path id pid[i] (identity for prepare_rays / first trace)
+void launch_pack_hits(HitBuf hb, uint32_t n, rt_hit* out, hipStream_t s);
+void launch_pack_rays(RayQueue q, uint32_t n, rt_ray* out, hipStream_t s);
+
+}  // namespace rt

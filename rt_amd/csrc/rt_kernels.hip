@@ -1,0 +1,357 @@
+// rt_kernels.hip — wavefront path-tracing kernels for gfx950 (wave64).
+//
+//   K0 k_raygen      Camera::get_ray                     src/camera.rs:231-254, :367-371, :140-165
+//   K1 k_trace       World::hit over the BVH             src/hittable.rs:135-149, :318-365, :408-495
+//   K2-4 k_shade     sky on miss, Material::scatter,     src/hittable.rs:84-93, src/material.rs:94-179,
+//                    russian_roulette, compaction        src/camera.rs:280-313
+//   K5 k_accumulate / k_resolve   render_pixel's mean    src/camera.rs:315-325
+//
+// One lane = one path.  Between bounces the survivors are compacted into the next queue with a
+// wave64 ballot + one atomic per wave.  Radiance is written once per path into its own slot and
+// summed per pixel in sample order, so a render is bit-reproducible.
+#include "rt_kernels.h"
+
+#include "rt_device.h"
+
+namespace rt {
+
+// ---------------------------------------------------------------------------------------------
+// K0 — primary rays
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, uint32_t n_paths, RayQueue q) {
+    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= n_paths) return;
+    uint32_t pixel = pid % pp.n_pixels, local = pid / pp.n_pixels;
+    uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
+    uint32_t x = pixel % pp.cam.width, y = pixel / pp.cam.width;
+    double ox = pp.jitter ? halton2(sample) : 0.0;      // rng_map[i] (src/camera.rs:239)
+    double oy = pp.jitter ? halton3(sample) : 0.0;
+    D3 p00 = ld3(pp.cam.pixel00), du = ld3(pp.cam.pixel_du), dv = ld3(pp.cam.pixel_dv), center = ld3(pp.cam.center);
+    D3 ps = add(add(p00, scale(du, (double)x + ox)), scale(dv, (double)y + oy));
+    D3 origin = center;
+    if (pp.jitter && !(pp.cam.defocus_angle <= 0.0)) {
+        // Vec3::random_in_unit_disc (src/vec3.rs:124-135); rejection k uses Philox block k of the
+        // primary-ray key (depth tag 0xFFFFFFFF); capped at 32 rejections like the oracle
+        RngKey key = {pp.seed, pixel, sample, DEPTH_PRIMARY};
+        D3 v = mk(1.0, 1.0, 1.0);
+        for (uint32_t it = 0; it < 32 && norm2(v) > 1.0; ++it) {
+            U4 r = rng_block(key, it);
+            v = mk(2.0 * u64_to_unit(r.x, r.y) - 1.0, 2.0 * u64_to_unit(r.z, r.w) - 1.0, 0.0);
+        }
+        origin = add(add(center, scale(ld3(pp.cam.defocus_u), v.x)), scale(ld3(pp.cam.defocus_v), v.y));
+    }
+    D3 dir = normalize(sub(ps, origin));                 // Ray::new normalises
+    q.o[0][pid] = origin.x; q.o[1][pid] = origin.y; q.o[2][pid] = origin.z;
+    q.d[0][pid] = dir.x; q.d[1][pid] = dir.y; q.d[2][pid] = dir.z;
+    q.thr[0][pid] = 1.0; q.thr[1][pid] = 1.0; q.thr[2][pid] = 1.0;
+    q.pid[pid] = pid;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    D3 o = ld3(rays[i].o), d = normalize(ld3(rays[i].d));
+    q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
+    q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
+    q.thr[0][i] = 1.0; q.thr[1][i] = 1.0; q.thr[2][i] = 1.0;
+    q.pid[i] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 — closest hit.  Per-lane traversal stack in LDS ([entry][lane]: conflict-free).
+// ---------------------------------------------------------------------------------------------
+// Slab test against an f64 box.  The interval is widened by a few ulps so that a primitive that
+// touches its own (exact) box is never culled by rounding; NaNs from 0*inf drop out of fmin/fmax.
+__device__ __forceinline__ bool slab64(const double* lo, const double* hi, D3 o, D3 inv, double t_min, double best,
+                                       double& t_near) {
+    double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+    tn -= fabs(tn) * 1e-15;
+    tf += fabs(tf) * 1e-15;
+    t_near = tn;
+    return tn <= tf && tf >= t_min && tn <= best;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, RayQueue q, uint32_t n, double t_min, double t_max,
+                                                  HitBuf hb, unsigned long long* counters) {
+    __shared__ uint32_t stack[BVH_MAX_DEPTH][BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * BLOCK + tid;
+    const bool active = i < n;
+    D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+    if (active) {
+        o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+    }
+    const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double best = t_max, bu = 0.0, bv = 0.0;
+    uint32_t prim = RT_MISS;
+    uint32_t cur = active ? S.root : REF_EMPTY;
+    int sp = 0;
+    uint32_t n_nodes = 0, n_prims = 0;
+
+    while (cur != REF_EMPTY) {
+        if (!(cur & REF_LEAF)) {
+            const Node64* nd = &S.nodes64[cur];
+            if (STATS) ++n_nodes;
+            const uint32_t cl = nd->left, cr = nd->right;
+            double tl, tr;
+            bool hl = slab64(nd->lo_l, nd->hi_l, o, inv, t_min, best, tl);
+            bool hr = cr != REF_EMPTY && slab64(nd->lo_r, nd->hi_r, o, inv, t_min, best, tr);
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                stack[sp++][tid] = left_first ? cr : cl;
+                cur = left_first ? cl : cr;
+            } else if (hl) {
+                cur = cl;
+            } else if (hr) {
+                cur = cr;
+            } else {
+                cur = sp ? stack[--sp][tid] : REF_EMPTY;
+            }
+        } else {
+            const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
+            if (STATS) n_prims += count;
+            if (cur & REF_SPHERE) {
+                for (uint32_t k = 0; k < count; ++k) {
+                    const SphGeom* g = &S.sphs[first + k];
+                    double t;
+                    if (sph_test(ld3(g->c), g->r, ld3(g->rot2), o, d, t_min, best, t)) { best = t; prim = g->prim; }
+                }
+            } else {
+                for (uint32_t k = 0; k < count; ++k) {
+                    const TriGeom* g = &S.tris[first + k];
+                    double t, u, v;
+                    if (tri_test(ld3(g->a), ld3(g->e1), ld3(g->e2), o, d, t_min, best, t, u, v)) {
+                        best = t; prim = g->prim; bu = u; bv = v;
+                    }
+                }
+            }
+            cur = sp ? stack[--sp][tid] : REF_EMPTY;
+        }
+    }
+    if (active) {
+        hb.t[i] = prim == RT_MISS ? 0.0 : best;
+        hb.prim[i] = prim;
+        hb.bu[i] = bu;
+        hb.bv[i] = bv;
+    }
+    if (STATS) {
+        unsigned long long a = n_nodes, b = n_prims;
+        for (int off = 32; off; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+        }
+        if ((tid & 63u) == 0) {
+            atomicAdd(&counters[0], a);
+            atomicAdd(&counters[1], b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2-K4 — shade + Russian roulette + compaction
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, uint32_t n,
+                                                 HitBuf hb, RayQueue qo, uint32_t* out_count, double* path_radiance) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = false;
+    D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
+    uint32_t pid = 0;
+    if (i < n) {
+        pid = qi.pid[i];
+        const D3 o = mk(qi.o[0][i], qi.o[1][i], qi.o[2][i]);
+        const D3 d = mk(qi.d[0][i], qi.d[1][i], qi.d[2][i]);
+        const D3 thr = mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
+        const uint32_t prim = hb.prim[i];
+        D3 L = mk(0.0, 0.0, 0.0);
+        if (prim == RT_MISS) {
+            // Camera::raycast miss branch (src/camera.rs:308-312)
+            D3 dir = normalize(d);
+            L = mul(thr, sky_color_toward(S.sky, dir));
+        } else {
+            const double t = hb.t[i];
+            SurfaceHit h;
+            h.bu = hb.bu[i]; h.bv = hb.bv[i];
+            h.is_sphere = prim < S.n_spheres;
+            h.ts = nullptr; h.ss = nullptr;
+            if (h.is_sphere) {                                      // Sphere::hit tail (src/hittable.rs:340-346)
+                const SphShade* ss = &S.sph_shade[prim];
+                h.ss = ss;
+                h.p = add(scale(d, t), o);
+                h.n = divs(sub(h.p, ld3(ss->c)), ss->r);
+                h.front = dot(d, h.n) < 0.0;
+                if (!h.front) h.n = neg(h.n);
+                h.material = ss->material;
+            } else {                                                // Triangle::hit tail (:463-464)
+                const TriShade* ts = &S.tri_shade[prim - S.n_spheres];
+                h.ts = ts;
+                h.p = add(o, scale(d, t));
+                h.n = ld3(ts->n);
+                h.front = dot(d, h.n) <= 0.0;
+                h.material = ts->material;
+            }
+            const rt_material* m = &S.mats[h.material];
+            const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
+            const uint32_t pixel = pid % pp.n_pixels, local = pid / pp.n_pixels;
+            RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
+            D3 att, dir;
+            if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
+                double ior = m->ior;
+                double ri = h.front ? 1.0 / ior : ior;
+                D3 din = normalize(d);
+                double c = fmin(-dot(din, h.n), 1.0);
+                double s = sqrt(1.0 - c * c);
+                bool cannot = ri * s > 1.0;
+                U4 b0 = rng_block(key, 0);
+                double noise = u64_to_unit(b0.x, b0.y);             // slot 0
+                if (cannot || reflectance(c, ri) > noise) {
+                    dir = reflect(din, h.n);
+                } else {
+                    dir = refract(din, h.n, ri);
+                    if (has_fuzz) {
+                        U4 b1 = rng_block(key, 1);
+                        D3 ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
+                                             2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
+                        dir = add(dir, scale(ru, m->fuzz));
+                    }
+                }
+                dir = normalize(dir);
+                att = mk(1.0, 1.0, 1.0);
+            } else {
+                D3 ru = mk(0, 0, 0);
+                if (kind == RT_MAT_LAMBERTIAN || has_fuzz) {        // Vec3::random_unit, slots 1,2,3 (src/vec3.rs:113-120)
+                    U4 b0 = rng_block(key, 0), b1 = rng_block(key, 1);
+                    ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
+                                      2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
+                }
+                if (kind == RT_MAT_LAMBERTIAN) {                    // src/material.rs:110-120
+                    dir = add(h.n, ru);
+                    if (near_zero(dir)) dir = h.n;
+                } else {                                            // Metal (:94-108)
+                    dir = reflect(d, h.n);
+                    if (has_fuzz) dir = add(dir, scale(ru, m->fuzz));
+                }
+                att = texture_value(S, m->texture, h);
+            }
+            dir = normalize(dir);                                   // Ray::new(point, dir)
+            if (depth < pp.cam.max_depth) {                         // src/camera.rs:300
+                double p = fmax(fmax(att.x, att.y), att.z);         // russian_roulette (:280-293)
+                U4 b2 = rng_block(key, 2);
+                if (u64_to_unit(b2.x, b2.y) < p) {                  // slot 4
+                    alive = true;
+                    nthr = mul(thr, divs(scale(att, 1.0), p));
+                    no = h.p;
+                    nd = dir;
+                }
+            }
+        }
+        if (!alive) {
+            path_radiance[3 * (size_t)pid + 0] = L.x;
+            path_radiance[3 * (size_t)pid + 1] = L.y;
+            path_radiance[3 * (size_t)pid + 2] = L.z;
+        }
+    }
+    // K4: wave64 ballot + prefix count, one atomic per wave
+    const unsigned long long mask = __ballot(alive);
+    if (mask) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(out_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0);
+        if (alive) {
+            const uint32_t j = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            qo.o[0][j] = no.x; qo.o[1][j] = no.y; qo.o[2][j] = no.z;
+            qo.d[0][j] = nd.x; qo.d[1][j] = nd.y; qo.d[2][j] = nd.z;
+            qo.thr[0][j] = nthr.x; qo.thr[1][j] = nthr.y; qo.thr[2][j] = nthr.z;
+            qo.pid[j] = pid;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 — per-pixel sum in sample order, and the final mean
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radiance, uint32_t n_pixels, uint32_t n_local,
+                                                      double* rgb_sum) {
+    uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
+    if (pixel >= n_pixels) return;
+    double r = rgb_sum[3 * (size_t)pixel], g = rgb_sum[3 * (size_t)pixel + 1], b = rgb_sum[3 * (size_t)pixel + 2];
+    for (uint32_t s = 0; s < n_local; ++s) {
+        const double* L = &path_radiance[3 * ((size_t)s * n_pixels + pixel)];
+        r += L[0]; g += L[1]; b += L[2];
+    }
+    rgb_sum[3 * (size_t)pixel] = r; rgb_sum[3 * (size_t)pixel + 1] = g; rgb_sum[3 * (size_t)pixel + 2] = b;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* mean, size_t n, double total_spp) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, uint32_t n, rt_hit* out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    rt_hit h;
+    h.t = hb.t[i]; h.prim = hb.prim[i]; h._pad = 0;
+    out[i] = h;
+}
+__global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, uint32_t n, rt_ray* out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    rt_ray r;
+    for (int k = 0; k < 3; ++k) { r.o[k] = q.o[k][i]; r.d[k] = q.d[k][i]; }
+    out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+void launch_raygen(const PassParams& pp, uint32_t n_paths, RayQueue q, hipStream_t s) {
+    if (!n_paths) return;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_paths)), dim3(BLOCK), 0, s, pp, n_paths, q);
+}
+void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, rays, n, q);
+}
+void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+                  unsigned long long* d_counters, hipStream_t s) {
+    if (!n) return;
+    if (stats)
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, q, n, t_min, t_max, hb, d_counters);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, q, n, t_min, t_max, hb, d_counters);
+}
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
+                  RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, pp, depth, q_in, n, hb, q_out, d_out_count,
+                       d_path_radiance);
+}
+void launch_accumulate(const double* d_path_radiance, uint32_t n_pixels, uint32_t n_local, double* d_rgb_sum,
+                       hipStream_t s) {
+    if (!n_pixels || !n_local) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(n_pixels)), dim3(BLOCK), 0, s, d_path_radiance, n_pixels, n_local,
+                       d_rgb_sum);
+}
+void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
+}
+void launch_pack_hits(HitBuf hb, uint32_t n, rt_hit* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_hits, dim3(grid_for(n)), dim3(BLOCK), 0, s, hb, n, out);
+}
+void launch_pack_rays(RayQueue q, uint32_t n, rt_ray* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, q, n, out);
+}
+
+}  // namespace rt

@@ -1,0 +1,105 @@
+// rt_layout.h — HBM data layout of a flattened scene and of the wavefront path state.
+// Shared by the host flattening code, the BVH builder and the kernels (all part of librt_hip.so).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+namespace rt {
+
+// ---- BVH child references ------------------------------------------------------------------
+// internal node : index into nodes[]                         (bit 31 clear)
+// leaf          : bit31 | sphere<<30 | (count-1)<<28 | first  (first indexes tris[] or sphs[], leaf order)
+// empty         : 0xFFFFFFFF
+constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_SPHERE = 0x40000000u;
+constexpr uint32_t REF_FIRST_MASK = 0x0FFFFFFFu;
+constexpr int MAX_LEAF = 4;
+// Traversal keeps one pending entry per ancestor, so the per-lane LDS stack needs `depth` entries;
+// the builder guarantees every child reference sits at depth <= BVH_MAX_DEPTH.
+constexpr int BVH_MAX_DEPTH = 32;
+
+// BVH2 node with both child boxes in the parent, f64 bounds: one 128-byte line per node.
+struct alignas(128) Node64 {
+    double lo_l[3], hi_l[3];
+    double lo_r[3], hi_r[3];
+    uint32_t left, right;
+    uint32_t _pad[6];
+};
+static_assert(sizeof(Node64) == 128, "Node64 layout");
+
+// BVH2 node with conservative f32 child boxes (rounded outward from f64): 64 bytes, two per line.
+struct alignas(64) Node32 {
+    float lo_l[3], hi_l[3];
+    float lo_r[3], hi_r[3];
+    uint32_t left, right;
+    uint32_t _pad[2];
+};
+static_assert(sizeof(Node32) == 64, "Node32 layout");
+
+// Triangle geometry in leaf order: a, e1 = b - a, e2 = c - a (src/hittable.rs:412-413), f64.
+struct alignas(16) TriGeom {
+    double a[3], e1[3], e2[3];
+    uint32_t prim;      // index in the caller's [spheres..., triangles...] order
+    uint32_t _pad;
+};
+static_assert(sizeof(TriGeom) == 80, "TriGeom layout");
+
+// Sphere geometry in leaf order; rot2 = third row of the texture rotation (NaN-uv rejection test).
+struct alignas(16) SphGeom {
+    double c[3], r;
+    double rot2[3];
+    uint32_t prim;
+    uint32_t _pad;
+};
+static_assert(sizeof(SphGeom) == 64, "SphGeom layout");
+
+// Shading records, indexed by primitive id (original order).
+struct alignas(16) TriShade {
+    double n[3];
+    double uv_left, uv_width, uv_bot, uv_height;   // bbox of the three vertex uvs (src/hittable.rs:469-476)
+    uint32_t material;
+    uint32_t _pad;
+};
+static_assert(sizeof(TriShade) == 64, "TriShade layout");
+
+struct alignas(16) SphShade {
+    double c[3], r;
+    double rot[9];
+    uint32_t material;
+    uint32_t _pad;
+};
+static_assert(sizeof(SphShade) == 112, "SphShade layout");
+
+struct DScene {
+    const Node64* nodes64;
+    const Node32* nodes32;
+    const TriGeom* tris;
+    const SphGeom* sphs;
+    const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres
+    const SphShade* sph_shade;   // [n_spheres]
+    const rt_material* mats;
+    const rt_texture* texs;
+    const uint8_t* texels;
+    uint32_t n_spheres, n_prims;
+    uint32_t root;               // REF_EMPTY for an empty scene, else 0
+    uint32_t _pad;
+    rt_sky sky;
+};
+
+// ---- wavefront path state (SoA, one slot per in-flight path) ---------------------------------
+struct RayQueue {
+    double* o[3];
+    double* d[3];
+    double* thr[3];     // path throughput
+    uint32_t* pid;      // path id inside the pass: local_sample * n_pixels + pixel
+};
+struct HitBuf {
+    double* t;
+    double* bu;         // triangle barycentrics u, v of the accepted hit
+    double* bv;
+    uint32_t* prim;     // RT_MISS = escaped to the sky
+};
+
+}  // namespace rt
