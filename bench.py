@@ -70,24 +70,25 @@ def cpu_baseline(desc, cam, target_seconds):
     orc = O.OracleScene(desc)
     build_s = time.time() - t0
     mid = cam.height // 2
-    # probe 2 rows, then size the band
+    # probe 2 rows at 1 spp, then size the sample: a band of rows, and more spp once the band is the whole frame
     t0 = time.time()
     orc.render(cam, 1, seed=1, mode=O.BVH_NOPRUNE, nthreads=cores, rows=(mid, min(cam.height, mid + 2)))
-    probe = max(time.time() - t0, 1e-3) / 2.0
+    probe = max(time.time() - t0, 1e-4) / 2.0
     rows = int(max(2, min(cam.height, target_seconds / probe)))
     y0 = max(0, mid - rows // 2)
     y1 = min(cam.height, y0 + rows)
+    cpu_spp = int(max(1, min(64, target_seconds / (probe * cam.height)))) if rows == cam.height else 1
     t0 = time.time()
-    _, st = orc.render(cam, 1, seed=1, mode=O.BVH_NOPRUNE, nthreads=cores, rows=(y0, y1), with_stats=True)
+    _, st = orc.render(cam, cpu_spp, seed=1, mode=O.BVH_NOPRUNE, nthreads=cores, rows=(y0, y1), with_stats=True)
     dt = time.time() - t0
-    samples = (y1 - y0) * cam.width
+    samples = (y1 - y0) * cam.width * cpu_spp
     # the same band with distance pruning, for the record (not the reference's behaviour)
     t0 = time.time()
-    orc.render(cam, 1, seed=1, mode=O.BVH_PRUNE, nthreads=cores, rows=(y0, y1))
+    orc.render(cam, cpu_spp, seed=1, mode=O.BVH_PRUNE, nthreads=cores, rows=(y0, y1))
     dt_prune = time.time() - t0
     orc.close()
     return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"rows {y0}..{y1} of the same {cam.width}x{cam.height} frame at 1 spp ({samples} samples, {dt:.1f} s)",
+            "sample": f"rows {y0}..{y1} of the same {cam.width}x{cam.height} frame at {cpu_spp} spp ({samples} samples, {dt:.1f} s)",
             "rays_per_s": float(st["ray_segments"]) / dt, "oracle_bvh_build_s": build_s,
             "value_with_distance_pruning": samples / dt_prune / 1e6}
 
@@ -126,20 +127,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from rt_amd.distributed import hip_render_sum, render_distributed
+
     def step(collect=False, spp_override=None):
-        stream = torch.cuda.current_stream().cuda_stream
-        o = cam.opts(spp=spp_override or spp, sample_offset=rank, sample_stride=world, seed=2024, device=local_rank,
-                     collect_stats=collect)
-        st = _abi.one(_abi.stats_dt)
-        rgb_sum.zero_()
-        check(L.rt_render_accumulate_device(w._h, _abi.ptr(cam.rec), _abi.ptr(o), C.c_void_p(rgb_sum.data_ptr()),
-                                            C.c_void_p(stream), _abi.ptr(st)))
-        if world > 1:
-            dist.reduce(rgb_sum, dst=0, op=dist.ReduceOp.SUM)       # RCCL sum-reduce over xGMI
-        if rank == 0:
-            check(L.rt_resolve_device(C.c_void_p(rgb_sum.data_ptr()), C.c_void_p(rgb_mean.data_ptr()), rgb_sum.numel(),
-                                      (spp_override or spp) * world, local_rank, C.c_void_p(stream)))
-        return st[0]
+        """One pass of the hot path: render this rank's sample indices, RCCL sum-reduce, resolve."""
+        box = {}
+
+        def render_sum(n_spp, offset, stride, seed, out_sum):
+            box["st"] = hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect)
+            return box["st"]
+
+        mean, st = render_distributed(render_sum, rgb_sum, spp_override or spp, seed=2024)
+        if mean is not None:
+            rgb_mean.copy_(mean)
+        return st
 
     for _ in range(args.warmup):
         step()

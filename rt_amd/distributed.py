@@ -1,0 +1,48 @@
+"""Sample-partitioned multi-GPU rendering: one process per GPU, `torch.distributed` (RCCL on ROCm).
+
+The path shards naturally: every camera sample is independent (`render_pixel` is a plain sum,
+src/camera.rs:316-324).  Rank r of N renders the global sample indices r, r+N, r+2N, ... of every
+pixel with the scene replicated in its HBM; the only exchange step is one sum-reduce of the
+per-pixel radiance-sum buffers, after which rank 0 divides by the total sample count.
+
+`render_sum` is injected so that the partition + reduce logic can be exercised on CPU (gloo) with a
+stand-in renderer in tests; on GPUs it is `hip_render_sum` below.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _abi
+
+
+def partition(spp_per_rank, rank, world):
+    """(spp, sample_offset, sample_stride) of this rank."""
+    return spp_per_rank, rank, world
+
+
+def hip_render_sum(world_handle, cam, spp, sample_offset, sample_stride, seed, out_sum, device, collect_stats=False):
+    """Adds this rank's radiance sums into the CUDA tensor out_sum through the C ABI."""
+    from ._lib import check, lib
+    o = cam.opts(spp=spp, sample_offset=sample_offset, sample_stride=sample_stride, seed=seed, device=device,
+                 collect_stats=collect_stats)
+    st = _abi.one(_abi.stats_dt)
+    stream = torch.cuda.current_stream().cuda_stream
+    check(lib().rt_render_accumulate_device(world_handle, _abi.ptr(cam.rec), _abi.ptr(o), C.c_void_p(out_sum.data_ptr()),
+                                            C.c_void_p(stream), _abi.ptr(st)))
+    return st[0]
+
+
+def render_distributed(render_sum, out_sum, spp_per_rank, seed=0):
+    """Every rank calls this.  render_sum(spp, offset, stride, seed, out_sum) must ADD the rank's
+    per-pixel sums into out_sum (a float64 tensor, zeroed here).  Returns (mean or None, stats):
+    the mean image only on rank 0."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    out_sum.zero_()
+    spp, off, stride = partition(spp_per_rank, rank, world)
+    stats = render_sum(spp, off, stride, seed, out_sum)
+    if world > 1:
+        dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
+    mean = out_sum / float(spp_per_rank * world) if rank == 0 else None
+    return mean, stats

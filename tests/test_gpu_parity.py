@@ -146,3 +146,54 @@ def test_stats_counters(cover):
     _, st = world.hit(rays, with_stats=True)
     assert int(st["ray_segments"]) == 10_000 and int(st["nodes_visited"]) > 10_000 and int(st["prims_tested"]) > 0
     assert float(st["seconds_trace"]) > 0.0
+
+
+def test_gpu_reproduces_golden_vectors(cover, mixed):
+    """tests/golden/golden_v1.npz (made by tests/golden/make_golden.py with the oracle, brute force)."""
+    import os
+    from golden.make_golden import golden_inputs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz"))
+    gi = golden_inputs()
+    h = gi["cover_cam"].trace_primary(cover[1], 0, jitter=True)
+    assert np.array_equal(h["prim"], gold["cover_jitter_prim"]) and np.array_equal(h["t"], gold["cover_jitter_t"])
+    h = gi["cover_cam"].trace_primary(cover[1], 0, jitter=False)
+    assert np.array_equal(h["prim"], gold["cover_debug_prim"]) and np.array_equal(h["t"], gold["cover_debug_t"])
+    h = mixed[1].hit(gi["mixed_rays"])
+    assert np.array_equal(h["prim"], gold["mixed_prim"]) and np.array_equal(h["t"], gold["mixed_t"])
+    hf = World.build(scenes.heightfield_scene(quads=48))
+    h = gi["hf_cam"].trace_primary(hf, 3, jitter=True)
+    assert np.array_equal(h["prim"], gold["hf_prim"]) and np.array_equal(h["t"], gold["hf_t"])
+    img, st = gi["mixed_cam"].render_image(mixed[1], spp=2, seed=3, with_stats=True)
+    assert int(st["ray_segments"]) == int(gold["mixed_render_segments"][0])
+    np.testing.assert_allclose(img, gold["mixed_render"], rtol=RTOL, atol=ATOL)
+
+
+def test_full_size_1m_triangle_frame_properties(oracle):
+    """BASELINE.json configs[2] at full size (1 002 528 triangles, 1920x1080): the oracle checks a
+    strided subset of the primary rays bit-exactly; the whole frame is checked through
+    size-independent properties (hit points lie on their triangle's plane and inside it,
+    determinism, sample-partition invariance, value range)."""
+    desc = scenes.heightfield_scene(quads=708)
+    world = World.build(desc)
+    cam = scenes.heightfield_camera(1920, 1080, 2, 50)
+    hits, rays = cam.trace_primary(world, 11, jitter=True, with_rays=True)
+    sub = np.arange(0, len(rays), 37)[:60_000]
+    orc = oracle.OracleScene(desc)
+    assert_hits_equal(hits[sub], orc.hit(rays[sub], mode=oracle.BVH_PRUNE))
+    hit = hits["prim"] != _abi.RT_MISS
+    assert 0.3 < hit.mean() < 0.8
+    tri = desc.triangles[hits["prim"][hit]]
+    p = rays["o"][hit] + rays["d"][hit] * hits["t"][hit][:, None]
+    plane = np.einsum("ij,ij->i", tri["n"], p - tri["a"])
+    assert np.abs(plane).max() < 1e-9
+    lo = np.minimum(np.minimum(tri["a"], tri["b"]), tri["c"]) - 1e-9
+    hi = np.maximum(np.maximum(tri["a"], tri["b"]), tri["c"]) + 1e-9
+    assert ((p >= lo) & (p <= hi)).all()
+    assert (np.einsum("ij,ij->i", tri["n"], rays["d"][hit]) < 0).all()          # one-sided: only front faces
+    a, sa = cam.render_image(world, spp=2, seed=8, with_stats=True)
+    b = cam.render_image(world, spp=2, seed=8, max_paths_in_flight=1920 * 1080)
+    assert np.array_equal(a, b)
+    halves = [cam.render_image(world, spp=1, seed=8, sample_offset=r, sample_stride=2) for r in range(2)]
+    np.testing.assert_allclose((halves[0] + halves[1]) / 2.0, a, rtol=1e-12, atol=1e-15)
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
+    assert int(sa["samples"]) == 2 * 1920 * 1080 and int(sa["ray_segments"]) > int(sa["samples"])
