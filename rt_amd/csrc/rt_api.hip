@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -462,7 +463,26 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         std::vector<rt_material> mats(materials, materials + n_materials);
         std::vector<rt_texture> texs(textures, textures + n_textures);
         std::vector<uint8_t> pool(texel_pool, texel_pool + texel_pool_bytes);
-        if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
+        // Node format: conservative f32 boxes (default; 64 B/node) or exact f64 boxes (128 B/node).
+        // RT_HIP_NODE_BOXES=f64 forces the latter (the two must give identical hits; tests compare).
+        // Coordinates beyond f32 range also fall back to f64 boxes.
+        const char* nb = getenv("RT_HIP_NODE_BOXES");
+        bool use32 = !(nb && strcmp(nb, "f64") == 0);
+        for (const Node64& nd : bvh.nodes)
+            for (int k = 0; k < 3 && use32; ++k) {
+                const double m = std::max(std::max(std::fabs(nd.lo_l[k]), std::fabs(nd.hi_l[k])),
+                                          nd.right == REF_EMPTY ? 0.0 : std::max(std::fabs(nd.lo_r[k]), std::fabs(nd.hi_r[k])));
+                if (!(m < 1e30)) use32 = false;
+            }
+        sc->d.nodes64 = nullptr;
+        sc->d.nodes32 = nullptr;
+        if (use32) {
+            std::vector<Node32> n32;
+            narrow_nodes(bvh.nodes, n32);
+            if ((rc = upload(sc, n32, &sc->d.nodes32))) return rc;
+        } else {
+            if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
+        }
         if ((rc = upload(sc, tg, &sc->d.tris))) return rc;
         if ((rc = upload(sc, sg, &sc->d.sphs))) return rc;
         if ((rc = upload(sc, tsh, &sc->d.tri_shade))) return rc;
@@ -470,10 +490,10 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         if ((rc = upload(sc, mats, &sc->d.mats))) return rc;
         if ((rc = upload(sc, texs, &sc->d.texs))) return rc;
         if ((rc = upload(sc, pool, &sc->d.texels))) return rc;
-        sc->d.nodes32 = nullptr;
         sc->d.n_spheres = (uint32_t)n_spheres;
         sc->d.n_prims = (uint32_t)n_prims;
         sc->d.root = n_prims ? 0u : REF_EMPTY;
+        sc->d.bvh_depth = bvh.depth;
         sc->d.sky = *sky;
         HIPCHK(hipDeviceSynchronize());
         const double tb2 = now_s();
@@ -482,7 +502,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.n_nodes = bvh.nodes.size();
         sc->info.bvh_depth = bvh.depth;
         sc->info.max_leaf_size = bvh.max_leaf;
-        sc->info.node_bytes = sizeof(Node64);
+        sc->info.node_bytes = use32 ? sizeof(Node32) : sizeof(Node64);
         sc->info.tri_bytes = sizeof(TriGeom);
         sc->info.sphere_bytes = sizeof(SphGeom);
         sc->info.build_seconds = tb1 - tb0;

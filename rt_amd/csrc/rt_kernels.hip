@@ -60,34 +60,85 @@ __global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, uint
 // ---------------------------------------------------------------------------------------------
 // K1 — closest hit.  Per-lane traversal stack in LDS ([entry][lane]: conflict-free).
 // ---------------------------------------------------------------------------------------------
-// Slab test against an f64 box.  The interval is widened by a few ulps so that a primitive that
-// touches its own (exact) box is never culled by rounding; NaNs from 0*inf drop out of fmin/fmax.
-__device__ __forceinline__ bool slab64(const double* lo, const double* hi, D3 o, D3 inv, double t_min, double best,
-                                       double& t_near) {
-    double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-    double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-    double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
-    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
-    tn -= fabs(tn) * 1e-15;
-    tf += fabs(tf) * 1e-15;
-    t_near = tn;
-    return tn <= tf && tf >= t_min && tn <= best;
-}
+// Ray-side state of the slab test, one policy per node format.
+//
+// Box64: f64 boxes.  The interval is widened by a few ulps so that a primitive touching its own
+// (exact) box is never culled by rounding; NaNs from 0*inf drop out of fmin/fmax.
+struct Box64 {
+    using Node = Node64;
+    D3 o, inv;
+    __device__ __forceinline__ void init(D3 o_, D3 d) { o = o_; inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+    static __device__ __forceinline__ const Node* nodes(const DScene& S) { return S.nodes64; }
+    __device__ __forceinline__ bool test(const double* lo, const double* hi, double t_min, double best, double& t_near) const {
+        double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+        double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+        double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+        double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+        double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+        tn *= tn > 0.0 ? 1.0 - 1e-15 : 1.0 + 1e-15;      // (multiplying keeps +-inf; subtracting would make NaN)
+        tf *= tf > 0.0 ? 1.0 + 1e-15 : 1.0 - 1e-15;
+        t_near = tn;
+        return !(tn > tf) && !(tf < t_min) && !(tn > best);
+    }
+};
 
-template <bool STATS>
-__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, RayQueue q, uint32_t n, double t_min, double t_max,
-                                                  HitBuf hb, unsigned long long* counters) {
-    __shared__ uint32_t stack[BVH_MAX_DEPTH][BLOCK];
+// Box32: conservative f32 test against boxes rounded OUTWARD to f32 (bvh_build.cpp: narrow_nodes).
+// It only culls; every accepted primitive is still intersected in f64, so (prim, t) stay bit-exact.
+// Error budget per slab plane b, with u = 2^-24, of = fl32(o), idf = fl32(1/d):
+//     T = fl32(fl32(b - of) * idf)   and the exact   t = (b - o)/d   satisfy
+//     |t - T| <= 3.1u |T| + 1.01u |of * idf|      (three roundings + the rounding of the origin)
+// so near = T - (|T| 2^-22 + c) and far = T + (|T| 2^-22 + c) with c = |of*idf| 2^-23 bracket t.
+// T -> T -/+ margin(T) is monotone, so the margins can be applied after min/max.  0*inf NaNs and
+// inf - inf NaNs drop out of fminf/fmaxf (IEEE minNum/maxNum), which only ever widens the interval;
+// the final comparisons are written negated so that a NaN accepts.
+struct Box32 {
+    using Node = Node32;
+    float ox, oy, oz, ix, iy, iz, cx, cy, cz;
+    __device__ __forceinline__ void init(D3 o, D3 d) {
+        ox = (float)o.x; oy = (float)o.y; oz = (float)o.z;
+        ix = (float)(1.0 / d.x); iy = (float)(1.0 / d.y); iz = (float)(1.0 / d.z);
+        cx = fmaf(fabsf(ox * ix), 0x1.0p-23f, 1e-30f);
+        cy = fmaf(fabsf(oy * iy), 0x1.0p-23f, 1e-30f);
+        cz = fmaf(fabsf(oz * iz), 0x1.0p-23f, 1e-30f);
+    }
+    static __device__ __forceinline__ const Node* nodes(const DScene& S) { return S.nodes32; }
+    __device__ __forceinline__ bool test(const float* lo, const float* hi, double t_min, double best, float& t_near) const {
+        const float r = 0x1.0p-22f;
+        float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
+        float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
+        float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
+        float nx = fminf(ax, bx), fx = fmaxf(ax, bx);
+        float ny = fminf(ay, by), fy = fmaxf(ay, by);
+        float nz = fminf(az, bz), fz = fmaxf(az, bz);
+        nx -= fmaf(fabsf(nx), r, cx); fx += fmaf(fabsf(fx), r, cx);
+        ny -= fmaf(fabsf(ny), r, cy); fy += fmaf(fabsf(fy), r, cy);
+        nz -= fmaf(fabsf(nz), r, cz); fz += fmaf(fabsf(fz), r, cz);
+        float tn = fmaxf(fmaxf(nx, ny), nz);
+        float tf = fminf(fminf(fx, fy), fz);
+        t_near = tn;
+        return !(tn > tf) && !((double)tf < t_min) && !((double)tn > best);
+    }
+};
+
+// One wave per workgroup: a workgroup's LDS is held until its slowest wave retires, and ray
+// lengths diverge a lot, so multi-wave groups strand LDS (and with it occupancy) behind stragglers.
+constexpr int TRACE_BLOCK = 64;
+
+template <class BoxT, bool STATS, int STACK>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene S, RayQueue q, uint32_t n, double t_min, double t_max,
+                                                        HitBuf hb, unsigned long long* counters) {
+    __shared__ uint32_t stack[STACK][TRACE_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * BLOCK + tid;
+    const uint32_t i = blockIdx.x * TRACE_BLOCK + tid;
     const bool active = i < n;
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
         o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
         d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
     }
-    const D3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    BoxT rb;
+    rb.init(o, d);
+    const typename BoxT::Node* nodes = BoxT::nodes(S);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t cur = active ? S.root : REF_EMPTY;
@@ -96,12 +147,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, RayQueue q, uint32_t 
 
     while (cur != REF_EMPTY) {
         if (!(cur & REF_LEAF)) {
-            const Node64* nd = &S.nodes64[cur];
+            const typename BoxT::Node* nd = &nodes[cur];
             if (STATS) ++n_nodes;
             const uint32_t cl = nd->left, cr = nd->right;
-            double tl, tr;
-            bool hl = slab64(nd->lo_l, nd->hi_l, o, inv, t_min, best, tl);
-            bool hr = cr != REF_EMPTY && slab64(nd->lo_r, nd->hi_r, o, inv, t_min, best, tr);
+            decltype(nd->lo_l[0] + 0) tl = 0, tr = 0;
+            bool hl = rb.test(nd->lo_l, nd->hi_l, t_min, best, tl);
+            bool hr = cr != REF_EMPTY && rb.test(nd->lo_r, nd->hi_r, t_min, best, tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
                 stack[sp++][tid] = left_first ? cr : cl;
@@ -321,13 +372,34 @@ void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t
     if (!n) return;
     hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, rays, n, q);
 }
+template <class BoxT, int STACK>
+static void launch_trace_s(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+                           unsigned long long* d_counters, hipStream_t s) {
+    const dim3 grid((n + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
+    if (stats)
+        hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, n, t_min, t_max, hb, d_counters);
+    else
+        hipLaunchKernelGGL((k_trace<BoxT, false, STACK>), grid, block, 0, s, S, q, n, t_min, t_max, hb, d_counters);
+}
+// The per-lane stack needs one entry per BVH level (S.bvh_depth <= BVH_MAX_DEPTH); a smaller
+// stack means less LDS per wave, i.e. more waves per CU.
+template <class BoxT>
+static void launch_trace_t(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+                           unsigned long long* d_counters, hipStream_t s) {
+    if (S.bvh_depth <= 16)
+        launch_trace_s<BoxT, 16>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.bvh_depth <= 24)
+        launch_trace_s<BoxT, 24>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+    else
+        launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+}
 void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
     if (!n) return;
-    if (stats)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, q, n, t_min, t_max, hb, d_counters);
+    if (S.nodes32)
+        launch_trace_t<Box32>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, q, n, t_min, t_max, hb, d_counters);
+        launch_trace_t<Box64>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
 }
 void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
                   RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s) {

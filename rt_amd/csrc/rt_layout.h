@@ -84,7 +84,7 @@ struct DScene {
     const uint8_t* texels;
     uint32_t n_spheres, n_prims;
     uint32_t root;               // REF_EMPTY for an empty scene, else 0
-    uint32_t _pad;
+    uint32_t bvh_depth;          // deepest child reference = traversal stack entries needed
     rt_sky sky;
 };
 

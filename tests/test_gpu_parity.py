@@ -179,7 +179,8 @@ def test_full_size_1m_triangle_frame_properties(oracle):
     hits, rays = cam.trace_primary(world, 11, jitter=True, with_rays=True)
     sub = np.arange(0, len(rays), 37)[:60_000]
     orc = oracle.OracleScene(desc)
-    assert_hits_equal(hits[sub], orc.hit(rays[sub], mode=oracle.BVH_PRUNE))
+    # (both sides re-normalise the already unit-length directions, like Ray::new would)
+    assert_hits_equal(world.hit(rays[sub]), orc.hit(rays[sub], mode=oracle.BVH_PRUNE))
     hit = hits["prim"] != _abi.RT_MISS
     assert 0.3 < hit.mean() < 0.8
     tri = desc.triangles[hits["prim"][hit]]
@@ -197,3 +198,74 @@ def test_full_size_1m_triangle_frame_properties(oracle):
     np.testing.assert_allclose((halves[0] + halves[1]) / 2.0, a, rtol=1e-12, atol=1e-15)
     assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
     assert int(sa["samples"]) == 2 * 1920 * 1080 and int(sa["ray_segments"]) > int(sa["samples"])
+
+
+def degenerate_rays(desc, seed=4):
+    """Rays that stress the conservative f32 box test: exactly axis-parallel directions, origins on
+    box / triangle planes, directions with denormal-small components, far and huge origins."""
+    k = np.arange(4000)
+    base = random_rays(len(k), seed)
+    o, d = base[:, :3].copy(), base[:, 3:].copy()
+    axis = np.eye(3)[k % 3] * np.where((k // 3) % 2 == 0, 1.0, -1.0)[:, None]
+    sel = k % 8
+    d[sel == 0] = axis[sel == 0]                                   # exactly axis-parallel (two zero components)
+    d[sel == 1] = axis[sel == 1] + 1e-18 * d[sel == 1]             # tiny off-axis components
+    d[sel == 2] = axis[sel == 2] + 1e-300 * d[sel == 2]            # reciprocal overflows f32 (and nearly f64)
+    o[sel == 3, 2] = -0.2                                          # on the ground plane ...
+    d[sel == 3, 2] = 0.0                                           # ... travelling inside it
+    far = sel == 4
+    nd = d[far] / np.linalg.norm(d[far], axis=1, keepdims=True)
+    o[far] = o[far] * 0.3 - nd * 1e6                               # a million units away, aimed at the scene
+    huge = sel == 5
+    o[huge] = o[huge] * 1e9
+    if len(desc.triangles):
+        tri = desc.triangles[k[sel == 6] % len(desc.triangles)]
+        inside = tri["a"] + 0.25 * (tri["b"] - tri["a"]) + 0.5 * (tri["c"] - tri["a"])
+        o[sel == 6] = inside + np.array([0.0, 0.0, 1.0])            # straight above an interior point
+        d[sel == 6] = (0.0, 0.0, -1.0)
+    if len(desc.spheres):
+        sp = desc.spheres[k[sel == 7] % len(desc.spheres)]
+        o[sel == 7] = sp["center"] + np.array([0.0, 0.0, 1.0]) * (sp["radius"][:, None] + 2.0)
+        d[sel == 7] = (0.0, 0.0, -1.0)                             # through the pole: |z'| ~ 1 (NaN-uv edge)
+    return np.concatenate([o, d], -1)
+
+
+def test_degenerate_rays_keep_bit_exact_hits(cover, mixed, oracle):
+    for desc, world, orc in (cover, mixed):
+        rays = degenerate_rays(desc)
+        assert_hits_equal(world.hit(rays), orc.hit(rays, mode=oracle.BRUTE))
+        assert_hits_equal(world.hit(rays, 0.0, 50.0), orc.hit(rays, 0.0, 50.0, mode=oracle.BRUTE))
+
+
+def test_exact_ties_keep_t_bit_exact(cover, oracle):
+    """Rays through a vertex shared by both ground triangles: the winner among equal-t primitives is
+    traversal-order dependent (the contract's stated exception, src/hittable.rs:142 half-open range);
+    t itself must still be bit-exact and the primitive must be one of the tied ones."""
+    desc, world, orc = cover
+    tri = desc.triangles
+    o = np.concatenate([tri["a"], tri["c"]]) + np.array([0.0, 0.0, 1.0])
+    rays = np.concatenate([o, np.tile([0.0, 0.0, -1.0], (len(o), 1))], -1)
+    g, r = world.hit(rays), orc.hit(rays, mode=oracle.BRUTE)
+    assert np.array_equal(g["t"], r["t"]) and (g["t"] == 1.0).all()
+    assert (g["prim"] >= len(desc.spheres)).all()
+
+
+def test_f32_and_f64_node_boxes_agree(monkeypatch, oracle):
+    """RT_HIP_NODE_BOXES=f64 selects exact f64 boxes; the default conservative f32 boxes must give
+    the same hits and the same image, bit for bit (boxes only cull)."""
+    desc = scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40)
+    w32 = World.build(desc)
+    monkeypatch.setenv("RT_HIP_NODE_BOXES", "f64")
+    w64 = World.build(desc)
+    monkeypatch.delenv("RT_HIP_NODE_BOXES")
+    assert w32.info()["node_bytes"] == 64 and w64.info()["node_bytes"] == 128
+    rays = np.concatenate([random_rays(40_000, 17), degenerate_rays(desc, 6)])
+    h32, h64 = w32.hit(rays), w64.hit(rays)
+    assert_hits_equal(h32, h64)
+    assert_hits_equal(h32, oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
+    # on ordinary rays the wider f32 margins accept (almost) no extra boxes
+    _, s32 = w32.hit(rays[:40_000], with_stats=True)
+    _, s64 = w64.hit(rays[:40_000], with_stats=True)
+    assert int(s64["nodes_visited"]) <= int(s32["nodes_visited"]) <= int(s64["nodes_visited"]) * 1.01
+    cam = Camera.new((9.0, -7.0, 4.0), (0.0, 0.0, 0.8), (0.0, 0.0, 1.0), 10.0, 0.3, 96, 64, 4, 12, 35.0)
+    assert np.array_equal(cam.render_image(w32, spp=3, seed=2), cam.render_image(w64, spp=3, seed=2))
