@@ -244,6 +244,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     pp.sample_offset = opts->sample_offset;
     pp.sample_stride = stride;
     pp.jitter = 1;
+    pp.tiled = 1;
 
     rt_stats st;
     memset(&st, 0, sizeof(st));
@@ -292,7 +293,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             cur ^= 1;
         }
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_accumulate(w.path_radiance, (uint32_t)npix, nl, d_rgb_sum, stream);
+        launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, stream);
         HIPCHK(hipEventRecord(w.ev[1], stream));
         HIPCHK(hipEventSynchronize(w.ev[1]));
         float ms_a = 0.f;
@@ -460,7 +461,19 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         const double tb1 = now_s();
 
         // ---- upload
-        std::vector<rt_material> mats(materials, materials + n_materials);
+        std::vector<ShadeMat> mats(n_materials);
+        for (size_t i = 0; i < n_materials; ++i) {
+            const rt_material& m = materials[i];
+            ShadeMat& r = mats[i];
+            memset(&r, 0, sizeof(r));
+            r.kind = m.kind; r.has_fuzz = m.has_fuzz ? 1u : 0u; r.fuzz = m.fuzz; r.ior = m.ior;
+            r.texture = m.texture;
+            r.tex_kind = RT_TEX_SOLID;
+            if (m.kind != RT_MAT_DIELECTRIC) {
+                r.tex_kind = textures[m.texture].kind;
+                for (int c = 0; c < 3; ++c) r.rgb[c] = textures[m.texture].rgb[c];
+            }
+        }
         std::vector<rt_texture> texs(textures, textures + n_textures);
         std::vector<uint8_t> pool(texel_pool, texel_pool + texel_pool_bytes);
         // Node format: conservative f32 boxes (default; 64 B/node) or exact f64 boxes (128 B/node).
@@ -610,6 +623,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.sample_stride = 1;
     pp.pass_base = 0;
     pp.jitter = jitter ? 1 : 0;
+    pp.tiled = 0;
     hipStream_t stream = nullptr;
     launch_raygen(pp, (uint32_t)npix, w.q[0], stream);
     launch_trace(sc->d, w.q[0], (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);

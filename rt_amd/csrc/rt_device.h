@@ -54,6 +54,10 @@ __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
 struct RngKey { uint64_t seed; uint32_t pixel, sample, depth; };
 // block b holds slots 2b (words x,y) and 2b+1 (words z,w)
 __device__ __forceinline__ U4 rng_block(const RngKey& k, uint32_t block) {
+#ifdef RT_EXP_NORNG
+    U4 o; o.x = k.pixel * 2654435761u + block; o.y = k.sample * 40503u + k.depth; o.z = o.x ^ 0x9E3779B9u; o.w = o.y * 2246822519u;
+    return o;
+#endif
     return philox4x32_10(k.pixel, k.sample, k.depth, block, (uint32_t)k.seed, (uint32_t)(k.seed >> 32));
 }
 
@@ -68,6 +72,32 @@ __device__ __forceinline__ double halton3(uint32_t index) {
     uint32_t i = index + 1, n = 0, d = 1;         // 3^13 > 2^20, fits in u32
     while (i) { n = n * 3u + i % 3u; i /= 3u; d *= 3u; }
     return (double)n / (double)d;
+}
+
+// ---- path slot -> pixel --------------------------------------------------------------------
+// Slots enumerate the full 8x8 tiles first (tile-major, row-major inside a tile), then the right
+// strip, then the bottom strip, so that a wave's 64 primary rays cover an 8x8 pixel block.
+__device__ __forceinline__ uint32_t slot_to_pixel(uint32_t slot, uint32_t W, uint32_t H, uint32_t tiled) {
+    if (!tiled) return slot;
+    const uint32_t W8 = W & ~7u, H8 = H & ~7u, nfull = W8 * H8;
+    uint32_t x, y;
+    if (slot < nfull) {
+        const uint32_t tile = slot >> 6, in = slot & 63u, tpr = W8 >> 3;
+        x = (tile % tpr) * 8u + (in & 7u);
+        y = (tile / tpr) * 8u + (in >> 3);
+    } else {
+        uint32_t r = slot - nfull;
+        const uint32_t wr = W - W8;
+        if (r < wr * H8) {
+            x = W8 + r % wr;
+            y = r / wr;
+        } else {
+            r -= wr * H8;
+            x = r % W;
+            y = H8 + r / W;
+        }
+    }
+    return y * W + x;
 }
 
 // ---- primitives -----------------------------------------------------------------------------
@@ -159,22 +189,26 @@ struct SurfaceHit {
     bool is_sphere;
     uint32_t material;
     // uv is evaluated lazily (only image textures read it)
-    double bu, bv;                 // triangle barycentrics
+    const double* bu;              // triangle barycentrics of this path's hit (HitBuf slots)
+    const double* bv;
     const TriShade* ts;
     const SphShade* ss;
 };
 
-__device__ __forceinline__ void surface_uv(const SurfaceHit& h, double& u, double& v) {
+// Out of line on purpose: acos/atan2 in f64 are register-hungry and only image textures need uv;
+// inlining them costs the whole shade kernel two waves per SIMD of occupancy.
+__device__ __noinline__ void surface_uv(const SurfaceHit& h, double& u, double& v) {
     if (h.is_sphere) {
         sphere_uv(h.n, h.ss->rot, u, v);
     } else {                        // bbox-of-uvs mapping (src/hittable.rs:469-481)
-        u = h.ts->uv_left + h.ts->uv_width * h.bu;
-        v = h.ts->uv_bot + h.ts->uv_height * h.bv;
+        u = h.ts->uv_left + h.ts->uv_width * *h.bu;
+        v = h.ts->uv_bot + h.ts->uv_height * *h.bv;
     }
 }
 
 // Texture::value for the three kinds (src/texture.rs:25-29, :61-74, :99-118)
 __device__ __forceinline__ D3 texture_value(const DScene& S, uint32_t ti, const SurfaceHit& h) {
+    // (solid root textures never get here: k_shade takes their colour from the ShadeMat record)
     for (int guard = 0; guard < 64; ++guard) {
         const rt_texture* t = &S.texs[ti];
         uint32_t kind = t->kind;

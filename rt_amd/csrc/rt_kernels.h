@@ -15,6 +15,7 @@ struct PassParams {
     uint32_t sample_offset, sample_stride;   // global sample = offset + (pass_base + local) * stride
     uint32_t pass_base;                      // first local sample of this pass
     uint32_t jitter;                         // 0: debug_ray (pixel centres, pinhole)
+    uint32_t tiled;                          // 1: path slots enumerate pixels in 8x8 tiles (coherent waves)
 };
 
 // K0: primary rays for path ids [0, n_paths) -> queue
@@ -28,7 +29,7 @@ void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double 
 void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
                   RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s);
 // K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order
-void launch_accumulate(const double* d_path_radiance, uint32_t n_pixels, uint32_t n_local_samples,
+void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local_samples,
                        double* d_rgb_sum, hipStream_t s);
 // K5b: mean = sum / total_spp
 void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);

@@ -21,7 +21,8 @@ namespace rt {
 __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, uint32_t n_paths, RayQueue q) {
     uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
     if (pid >= n_paths) return;
-    uint32_t pixel = pid % pp.n_pixels, local = pid / pp.n_pixels;
+    uint32_t local = pid / pp.n_pixels;
+    uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
     uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
     uint32_t x = pixel % pp.cam.width, y = pixel / pp.cam.width;
     double ox = pp.jitter ? halton2(sample) : 0.0;      // rng_map[i] (src/camera.rs:239)
@@ -217,17 +218,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
         pid = qi.pid[i];
         const D3 o = mk(qi.o[0][i], qi.o[1][i], qi.o[2][i]);
         const D3 d = mk(qi.d[0][i], qi.d[1][i], qi.d[2][i]);
-        const D3 thr = mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
+        // depth 0: the throughput is (1,1,1) by construction (k_raygen writes it, nobody needs to read it)
+        const D3 thr = depth == 0 ? mk(1.0, 1.0, 1.0) : mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
         const uint32_t prim = hb.prim[i];
         D3 L = mk(0.0, 0.0, 0.0);
         if (prim == RT_MISS) {
             // Camera::raycast miss branch (src/camera.rs:308-312)
             D3 dir = normalize(d);
+#ifdef RT_EXP_NOSKY
+            L = mul(thr, mk(0.5 + 0.1 * dir.z, 0.6, 0.7));
+#else
             L = mul(thr, sky_color_toward(S.sky, dir));
+#endif
         } else {
             const double t = hb.t[i];
             SurfaceHit h;
-            h.bu = hb.bu[i]; h.bv = hb.bv[i];
+            h.bu = &hb.bu[i]; h.bv = &hb.bv[i];
             h.is_sphere = prim < S.n_spheres;
             h.ts = nullptr; h.ss = nullptr;
             if (h.is_sphere) {                                      // Sphere::hit tail (src/hittable.rs:340-346)
@@ -246,9 +252,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
                 h.front = dot(d, h.n) <= 0.0;
                 h.material = ts->material;
             }
-            const rt_material* m = &S.mats[h.material];
+            const ShadeMat* m = &S.mats[h.material];
             const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
-            const uint32_t pixel = pid % pp.n_pixels, local = pid / pp.n_pixels;
+            const uint32_t local = pid / pp.n_pixels;
+            const uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
             RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
             D3 att, dir;
             if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
                     dir = reflect(d, h.n);
                     if (has_fuzz) dir = add(dir, scale(ru, m->fuzz));
                 }
-                att = texture_value(S, m->texture, h);
+                att = m->tex_kind == RT_TEX_SOLID ? ld3(m->rgb) : texture_value(S, m->texture, h);
             }
             dir = normalize(dir);                                   // Ray::new(point, dir)
             if (depth < pp.cam.max_depth) {                         // src/camera.rs:300
@@ -327,13 +334,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
 // ---------------------------------------------------------------------------------------------
 // K5 — per-pixel sum in sample order, and the final mean
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radiance, uint32_t n_pixels, uint32_t n_local,
-                                                      double* rgb_sum) {
-    uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
-    if (pixel >= n_pixels) return;
+__global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radiance, uint32_t n_pixels, uint32_t W, uint32_t H,
+                                                      uint32_t tiled, uint32_t n_local, double* rgb_sum) {
+    uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= n_pixels) return;
+    const uint32_t pixel = slot_to_pixel(slot, W, H, tiled);
     double r = rgb_sum[3 * (size_t)pixel], g = rgb_sum[3 * (size_t)pixel + 1], b = rgb_sum[3 * (size_t)pixel + 2];
     for (uint32_t s = 0; s < n_local; ++s) {
-        const double* L = &path_radiance[3 * ((size_t)s * n_pixels + pixel)];
+        const double* L = &path_radiance[3 * ((size_t)s * n_pixels + slot)];
         r += L[0]; g += L[1]; b += L[2];
     }
     rgb_sum[3 * (size_t)pixel] = r; rgb_sum[3 * (size_t)pixel + 1] = g; rgb_sum[3 * (size_t)pixel + 2] = b;
@@ -407,11 +415,11 @@ void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueu
     hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, pp, depth, q_in, n, hb, q_out, d_out_count,
                        d_path_radiance);
 }
-void launch_accumulate(const double* d_path_radiance, uint32_t n_pixels, uint32_t n_local, double* d_rgb_sum,
+void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
                        hipStream_t s) {
-    if (!n_pixels || !n_local) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(n_pixels)), dim3(BLOCK), 0, s, d_path_radiance, n_pixels, n_local,
-                       d_rgb_sum);
+    if (!pp.n_pixels || !n_local) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(pp.n_pixels)), dim3(BLOCK), 0, s, d_path_radiance, pp.n_pixels,
+                       pp.cam.width, pp.cam.height, pp.tiled, n_local, d_rgb_sum);
 }
 void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
     if (!n) return;

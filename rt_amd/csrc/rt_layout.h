@@ -72,6 +72,17 @@ struct alignas(16) SphShade {
 };
 static_assert(sizeof(SphShade) == 112, "SphShade layout");
 
+// Material with the root texture node folded in: a solid-colour material (the common case) is
+// shaded from this one 64-byte record without touching the texture table.
+struct alignas(16) ShadeMat {
+    uint32_t kind, has_fuzz;
+    uint32_t texture, tex_kind;     // root texture node and its kind
+    double fuzz, ior;
+    double rgb[3];                  // root colour when tex_kind == RT_TEX_SOLID
+    uint32_t _pad[2];
+};
+static_assert(sizeof(ShadeMat) == 64, "ShadeMat layout");
+
 struct DScene {
     const Node64* nodes64;
     const Node32* nodes32;
@@ -79,7 +90,7 @@ struct DScene {
     const SphGeom* sphs;
     const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres
     const SphShade* sph_shade;   // [n_spheres]
-    const rt_material* mats;
+    const ShadeMat* mats;
     const rt_texture* texs;
     const uint8_t* texels;
     uint32_t n_spheres, n_prims;
