@@ -96,7 +96,7 @@ struct Workspace {
     RayQueue q[2];
     HitBuf hb;
     double* path_radiance = nullptr;
-    uint32_t* counters = nullptr;             // 2 counters, 256 B apart
+    uint32_t* counters = nullptr;             // 2 sets of NSHARD counters, 128 B apart
     unsigned long long* stat_counters = nullptr;   // [2], own 256-B block
     uint32_t* h_count = nullptr;              // pinned
     unsigned long long* h_stat = nullptr;     // pinned [2]
@@ -128,7 +128,7 @@ void free_workspace(Workspace& w) {
 int ensure_workspace(rt_scene* sc, size_t paths) {
     Workspace& w = sc->ws;
     if (!w.h_count) {
-        HIPCHK(hipHostMalloc((void**)&w.h_count, 256, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&w.h_count, COUNTER_BYTES, hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&w.h_stat, 256, hipHostMallocDefault));
         for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
     }
@@ -139,8 +139,9 @@ int ensure_workspace(rt_scene* sc, size_t paths) {
         w.capacity = 0;
     }
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t dsz = up(paths * sizeof(double)), usz = up(paths * sizeof(uint32_t));
-    size_t total = 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 3 * 256;
+    const size_t slots = paths + QUEUE_SLACK;     // sharded queues pad every shard to a multiple of 64
+    const size_t dsz = up(slots * sizeof(double)), usz = up(slots * sizeof(uint32_t));
+    size_t total = 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 2 * COUNTER_BYTES + 256;
     char* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total);
     if (e != hipSuccess) {
@@ -161,7 +162,7 @@ int ensure_workspace(rt_scene* sc, size_t paths) {
     w.hb.bv = (double*)take(dsz);
     w.hb.prim = (uint32_t*)take(usz);
     w.path_radiance = (double*)take(up(3 * paths * sizeof(double)));
-    w.counters = (uint32_t*)take(512);
+    w.counters = (uint32_t*)take(2 * COUNTER_BYTES);
     w.stat_counters = (unsigned long long*)take(256);
     w.capacity = paths;
     return RT_OK;
@@ -260,15 +261,17 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipEventRecord(w.ev[1], stream));
         st.launches++;
         int cur = 0;
+        QueueMap qm = queue_map_single(n);
         for (uint32_t depth = 0; depth <= cam->max_depth && n > 0; ++depth) {
-            // the survivors' counter: its own 256-byte block, zeroed on the stream before every use
-            uint32_t* d_count = w.counters + 64 * (depth & 1u);
-            HIPCHK(hipMemsetAsync(d_count, 0, 256, stream));
+            // the survivors' counters (one per output shard), zeroed on the stream before every use
+            uint32_t* d_count = w.counters + (COUNTER_BYTES / 4) * (depth & 1u);
+            const ShardBases ob = shard_bases_for(qm);
+            HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, stream));
             HIPCHK(hipEventRecord(w.ev[2], stream));
-            launch_trace(sc->d, w.q[cur], n, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
+            launch_trace(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
             HIPCHK(hipEventRecord(w.ev[3], stream));
-            launch_shade(sc->d, pp, depth, w.q[cur], n, w.hb, w.q[cur ^ 1], d_count, w.path_radiance, stream);
-            HIPCHK(hipMemcpyAsync(w.h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            launch_shade(sc->d, pp, depth, w.q[cur], qm, w.hb, w.q[cur ^ 1], ob, d_count, w.path_radiance, stream);
+            HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipEventRecord(w.ev[4], stream));
             HIPCHK(hipStreamSynchronize(stream));
             HIPCHK(hipGetLastError());
@@ -289,7 +292,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.trace_launches++;
             st.launches += 2;
             st.ray_segments += n;
-            n = *w.h_count;
+            qm = queue_map_from_counts(ob, w.h_count, &n);
             cur ^= 1;
         }
         HIPCHK(hipEventRecord(w.ev[0], stream));
@@ -572,7 +575,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
         HIPCHK(hipMemcpyAsync(d_rays, rays + off, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
         launch_prepare_rays(d_rays, m, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_trace(sc->d, w.q[0], m, t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
+        launch_trace(sc->d, w.q[0], queue_map_single(m), t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
         HIPCHK(hipEventRecord(w.ev[1], stream));
         launch_pack_hits(w.hb, m, d_hits, stream);
         HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -626,7 +629,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.tiled = 0;
     hipStream_t stream = nullptr;
     launch_raygen(pp, (uint32_t)npix, w.q[0], stream);
-    launch_trace(sc->d, w.q[0], (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
+    launch_trace(sc->d, w.q[0], queue_map_single((uint32_t)npix), cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
     launch_pack_hits(w.hb, (uint32_t)npix, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {

@@ -100,6 +100,21 @@ __device__ __forceinline__ uint32_t slot_to_pixel(uint32_t slot, uint32_t W, uin
     return y * W + x;
 }
 
+// ---- sharded queue addressing ----------------------------------------------------------------
+// wave_first: logical index of the wave's lane 0 (multiple of 64, wave-uniform).  Returns whether
+// this lane holds a live entry and its physical slot.
+__device__ __forceinline__ bool queue_slot(const QueueMap& m, uint32_t wave_first, uint32_t lane, uint32_t& slot) {
+    uint32_t lo = 0, hi = NSHARD;                 // largest k with lprefix[k] <= wave_first
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {              // log2(NSHARD)
+        const uint32_t mid = (lo + hi) >> 1;
+        if (m.lprefix[mid] <= wave_first) lo = mid; else hi = mid;
+    }
+    const uint32_t off = wave_first - m.lprefix[lo] + lane;
+    slot = m.base[lo] + off;
+    return wave_first < m.lprefix[NSHARD] && off < m.count[lo];
+}
+
 // ---- primitives -----------------------------------------------------------------------------
 // Triangle::hit (src/hittable.rs:408-495) on the precomputed edges; returns true and (dist,u,v).
 __device__ __forceinline__ bool tri_test(D3 a, D3 e1, D3 e2, D3 o, D3 d, double lo, double hi,

@@ -23,11 +23,18 @@ void launch_raygen(const PassParams& pp, uint32_t n_paths, RayQueue q, hipStream
 // World::hit input for rt_trace_closest: normalise host rays into a queue (Ray::new)
 void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t s);
 // K1: closest hit for queue[0, n)
-void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb,
+void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
                   bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
+// sharded-queue bookkeeping (host): a dense queue of n entries; the output bases of a shade launch
+// over `in`; the map of the queue that launch produced, from its NSHARD counters (32 u32 apart)
+QueueMap queue_map_single(uint32_t n);
+ShardBases shard_bases_for(const QueueMap& in);
+QueueMap queue_map_from_counts(const ShardBases& bases, const uint32_t* counts, uint32_t* total);
+constexpr size_t QUEUE_SLACK = 64 * NSHARD;   // physical slots beyond the path count a sharded queue may need
+constexpr size_t COUNTER_BYTES = 128 * NSHARD;
 // K2+K3+K4: shade (miss -> sky, hit -> scatter + Russian roulette) and compact survivors into q_out
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
-                  RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s);
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueMap& qm, HitBuf hb,
+                  RayQueue q_out, const ShardBases& out_bases, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s);
 // K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local_samples,
                        double* d_rgb_sum, hipStream_t s);

@@ -126,12 +126,12 @@ struct Box32 {
 constexpr int TRACE_BLOCK = 64;
 
 template <class BoxT, bool STATS, int STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene S, RayQueue q, uint32_t n, double t_min, double t_max,
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
                                                         HitBuf hb, unsigned long long* counters) {
     __shared__ uint32_t stack[STACK][TRACE_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * TRACE_BLOCK + tid;
-    const bool active = i < n;
+    uint32_t i = 0;
+    const bool active = queue_slot(qm, blockIdx.x * TRACE_BLOCK, tid, i);
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
         o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
@@ -208,13 +208,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene S, RayQueue q, uin
 // ---------------------------------------------------------------------------------------------
 // K2-K4 — shade + Russian roulette + compaction
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, uint32_t n,
-                                                 HitBuf hb, RayQueue qo, uint32_t* out_count, double* path_radiance) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueMap qm,
+                                                 HitBuf hb, RayQueue qo, ShardBases ob, uint32_t* out_counts,
+                                                 double* path_radiance) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_first = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) & ~63u);
+    uint32_t i = 0;
+    const bool active = queue_slot(qm, wave_first, lane, i);
     bool alive = false;
     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
     uint32_t pid = 0;
-    if (i < n) {
+    if (active) {
         pid = qi.pid[i];
         const D3 o = mk(qi.o[0][i], qi.o[1][i], qi.o[2][i]);
         const D3 d = mk(qi.d[0][i], qi.d[1][i], qi.d[2][i]);
@@ -314,13 +318,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
             path_radiance[3 * (size_t)pid + 2] = L.z;
         }
     }
-    // K4: wave64 ballot + prefix count, one atomic per wave
+    // K4: wave64 ballot + prefix count, one atomic per wave, on the counter of the wave's output
+    // shard (counters sit 128 B apart)
     const unsigned long long mask = __ballot(alive);
     if (mask) {
-        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t shard = (wave_first >> 6) & (NSHARD - 1);
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(out_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, 0);
+        if (lane == 0) base = atomicAdd(out_counts + 32 * shard, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0) + ob.base[shard];
         if (alive) {
             const uint32_t j = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             qo.o[0][j] = no.x; qo.o[1][j] = no.y; qo.o[2][j] = no.z;
@@ -381,39 +386,76 @@ void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t
     hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, rays, n, q);
 }
 template <class BoxT, int STACK>
-static void launch_trace_s(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+static void launch_trace_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                            unsigned long long* d_counters, hipStream_t s) {
-    const dim3 grid((n + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
+    const dim3 grid(qm.lprefix[NSHARD] / TRACE_BLOCK), block(TRACE_BLOCK);
     if (stats)
-        hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, n, t_min, t_max, hb, d_counters);
+        hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
     else
-        hipLaunchKernelGGL((k_trace<BoxT, false, STACK>), grid, block, 0, s, S, q, n, t_min, t_max, hb, d_counters);
+        hipLaunchKernelGGL((k_trace<BoxT, false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
 }
 // The per-lane stack needs one entry per BVH level (S.bvh_depth <= BVH_MAX_DEPTH); a smaller
 // stack means less LDS per wave, i.e. more waves per CU.
 template <class BoxT>
-static void launch_trace_t(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                            unsigned long long* d_counters, hipStream_t s) {
     if (S.bvh_depth <= 16)
-        launch_trace_s<BoxT, 16>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+        launch_trace_s<BoxT, 16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else if (S.bvh_depth <= 24)
-        launch_trace_s<BoxT, 24>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+        launch_trace_s<BoxT, 24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else
-        launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+        launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }
-void launch_trace(const DScene& S, RayQueue q, uint32_t n, double t_min, double t_max, HitBuf hb, bool stats,
+void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
-    if (!n) return;
+    if (!qm.lprefix[NSHARD]) return;
     if (S.nodes32)
-        launch_trace_t<Box32>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+        launch_trace_t<Box32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else
-        launch_trace_t<Box64>(S, q, n, t_min, t_max, hb, stats, d_counters, s);
+        launch_trace_t<Box64>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, uint32_t n, HitBuf hb,
-                  RayQueue q_out, uint32_t* d_out_count, double* d_path_radiance, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(BLOCK), 0, s, S, pp, depth, q_in, n, hb, q_out, d_out_count,
-                       d_path_radiance);
+
+QueueMap queue_map_single(uint32_t n) {
+    QueueMap m;
+    const uint32_t padded = (n + 63u) & ~63u;
+    for (int k = 0; k < NSHARD; ++k) { m.lprefix[k] = k ? padded : 0; m.base[k] = 0; m.count[k] = 0; }
+    m.lprefix[NSHARD] = padded;
+    m.count[0] = n;
+    return m;
+}
+
+ShardBases shard_bases_for(const QueueMap& in) {
+    // output shard k receives the survivors of the input waves w with w % NSHARD == k
+    ShardBases b;
+    const uint32_t nw = in.lprefix[NSHARD] / 64;
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < (uint32_t)NSHARD; ++k) {
+        b.base[k] = acc;
+        acc += 64u * (nw > k ? (nw - k + NSHARD - 1) / NSHARD : 0u);
+    }
+    return b;
+}
+
+QueueMap queue_map_from_counts(const ShardBases& bases, const uint32_t* counts /* stride 32 */, uint32_t* total) {
+    QueueMap m;
+    uint32_t l = 0, t = 0;
+    for (int k = 0; k < NSHARD; ++k) {
+        const uint32_t c = counts[32 * k];
+        m.lprefix[k] = l;
+        m.base[k] = bases.base[k];
+        m.count[k] = c;
+        l += (c + 63u) & ~63u;
+        t += c;
+    }
+    m.lprefix[NSHARD] = l;
+    *total = t;
+    return m;
+}
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueMap& qm, HitBuf hb,
+                  RayQueue q_out, const ShardBases& out_bases, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s) {
+    if (!qm.lprefix[NSHARD]) return;
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(qm.lprefix[NSHARD])), dim3(BLOCK), 0, s, S, pp, depth, q_in, qm, hb, q_out,
+                       out_bases, d_out_counts, d_path_radiance);
 }
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
                        hipStream_t s) {

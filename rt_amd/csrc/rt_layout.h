@@ -106,6 +106,20 @@ struct RayQueue {
     double* thr[3];     // path throughput
     uint32_t* pid;      // path id inside the pass: local_sample * n_pixels + pixel
 };
+// A ray queue is stored as NSHARD independently appended segments so that compaction spreads its
+// (returning) atomics over NSHARD counters: one counter saturates at ~88 appends/us on MI355X, which
+// at one append per wave cost more than the shading itself.  Logical indices are padded so that a
+// wave (64 consecutive logical indices) never straddles two shards.
+constexpr int NSHARD = 64;
+struct QueueMap {
+    uint32_t lprefix[NSHARD + 1];   // logical start of shard k (multiple of 64); [NSHARD] = logical size
+    uint32_t base[NSHARD];          // first physical slot of shard k
+    uint32_t count[NSHARD];         // live entries in shard k
+};
+struct ShardBases {
+    uint32_t base[NSHARD];          // first physical slot of each OUTPUT shard
+};
+
 struct HitBuf {
     double* t;
     double* bu;         // triangle barycentrics u, v of the accepted hit
