@@ -10,7 +10,13 @@ namespace {
 
 constexpr int NBINS = 16;
 constexpr double COST_TRAVERSE = 1.0;
-constexpr double COST_PRIM = 1.0;
+#ifndef RT_COST_PRIM
+#define RT_COST_PRIM 1.0
+#endif
+#ifndef RT_LEAF_MAX
+#define RT_LEAF_MAX MAX_LEAF
+#endif
+constexpr double COST_PRIM = RT_COST_PRIM;
 constexpr double INF = std::numeric_limits<double>::infinity();
 
 struct Box {
@@ -83,7 +89,7 @@ struct Builder {
             bounds.grow(p.lo, p.hi);
             cb.grow_point(&cent[3 * idx[i]]);
         }
-        const bool can_leaf = count <= (size_t)MAX_LEAF && homogeneous(first, count);
+        const bool can_leaf = count <= (size_t)RT_LEAF_MAX && homogeneous(first, count);
         if (count == 1) return make_leaf(first, count, depth);
 
         // --- binned SAH over the three axes
@@ -193,7 +199,7 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
     Builder B(boxes, n_spheres, out);
     Box bounds;
     // Probe: would the whole scene be a single leaf?  Then wrap it so that node 0 always exists.
-    bool single = n == 1 || (n <= (size_t)MAX_LEAF && B.homogeneous(0, n));
+    bool single = n == 1 || (n <= (size_t)RT_LEAF_MAX && B.homogeneous(0, n));
     if (single) {
         Box b;
         for (size_t i = 0; i < n; ++i) b.grow(boxes[i].lo, boxes[i].hi);

@@ -268,7 +268,10 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             const ShardBases ob = shard_bases_for(qm);
             HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, stream));
             HIPCHK(hipEventRecord(w.ev[2], stream));
-            launch_trace(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
+            if (depth == 0 && !getenv("RT_HIP_NO_PACKET"))   // camera rays of 8x8 tiles: coherent
+                launch_trace_packet(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
+            else
+                launch_trace(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
             HIPCHK(hipEventRecord(w.ev[3], stream));
             launch_shade(sc->d, pp, depth, w.q[cur], qm, w.hb, w.q[cur ^ 1], ob, d_count, w.path_radiance, stream);
             HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, stream));

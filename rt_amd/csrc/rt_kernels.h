@@ -25,6 +25,9 @@ void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t
 // K1: closest hit for queue[0, n)
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
                   bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
+// K1p: the same for coherent waves (camera rays in 8x8 tiles): wave-level packet traversal through the scalar cache
+void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
+                         bool stats, unsigned long long* d_counters, hipStream_t s);
 // sharded-queue bookkeeping (host): a dense queue of n entries; the output bases of a shade launch
 // over `in`; the map of the queue that launch produced, from its NSHARD counters (32 u32 apart)
 QueueMap queue_map_single(uint32_t n);
