@@ -245,4 +245,66 @@ void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out) {
     }
 }
 
+bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, QuantGrid& g, double max_inflation) {
+    if (in.empty()) return false;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const Node32& n : in)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], n.lo_l[k]); hi[k] = std::max(hi[k], n.hi_l[k]);
+            if (n.right != REF_EMPTY) { lo[k] = std::min(lo[k], n.lo_r[k]); hi[k] = std::max(hi[k], n.hi_r[k]); }
+        }
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return false;
+        g.origin[k] = lo[k];
+        double cell = ((double)hi[k] - (double)lo[k]) / 65535.0 * 1.0001;
+        g.cell[k] = round_up(cell > 0.0 ? cell : 1e-30);
+    }
+    auto dec = [&](uint32_t q, int k) { return std::fmaf((float)q, g.cell[k], g.origin[k]); };   // == device decode
+    auto qlo = [&](float v, int k, uint16_t& o) {
+        double q = std::floor(((double)v - (double)g.origin[k]) / (double)g.cell[k]);
+        long qi = (long)std::min(std::max(q, 0.0), 65535.0);
+        while (qi > 0 && dec((uint32_t)qi, k) > v) --qi;
+        if (dec((uint32_t)qi, k) > v) return false;
+        o = (uint16_t)qi;
+        return true;
+    };
+    auto qhi = [&](float v, int k, uint16_t& o) {
+        double q = std::ceil(((double)v - (double)g.origin[k]) / (double)g.cell[k]);
+        long qi = (long)std::min(std::max(q, 0.0), 65535.0);
+        while (qi < 65535 && dec((uint32_t)qi, k) < v) ++qi;
+        if (dec((uint32_t)qi, k) < v) return false;
+        o = (uint16_t)qi;
+        return true;
+    };
+    std::vector<Node16> res(in.size());
+    double infl = 0.0;
+    size_t n_leaf = 0;
+    auto area = [](const float* l, const float* h, double pad[3]) {
+        double e[3];
+        for (int k = 0; k < 3; ++k) e[k] = (double)h[k] - (double)l[k] + 2.0 * pad[k];
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    };
+    double pad0[3] = {0, 0, 0}, pad1[3] = {g.cell[0], g.cell[1], g.cell[2]};
+    for (size_t i = 0; i < in.size(); ++i) {
+        const Node32& a = in[i];
+        Node16& b = res[i];
+        const bool has_r = a.right != REF_EMPTY;
+        for (int k = 0; k < 3; ++k) {
+            if (!qlo(a.lo_l[k], k, b.lo_l[k]) || !qhi(a.hi_l[k], k, b.hi_l[k])) return false;
+            if (has_r) {
+                if (!qlo(a.lo_r[k], k, b.lo_r[k]) || !qhi(a.hi_r[k], k, b.hi_r[k])) return false;
+            } else {
+                b.lo_r[k] = 65535; b.hi_r[k] = 0;
+            }
+        }
+        b.left = a.left;
+        b.right = a.right;
+        if (a.left & REF_LEAF) { double s0 = area(a.lo_l, a.hi_l, pad0); if (s0 > 0) { infl += area(a.lo_l, a.hi_l, pad1) / s0; ++n_leaf; } }
+        if (has_r && (a.right & REF_LEAF)) { double s0 = area(a.lo_r, a.hi_r, pad0); if (s0 > 0) { infl += area(a.lo_r, a.hi_r, pad1) / s0; ++n_leaf; } }
+    }
+    if (n_leaf && infl / (double)n_leaf > max_inflation) return false;
+    out.swap(res);
+    return true;
+}
+
 }  // namespace rt

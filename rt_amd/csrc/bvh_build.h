@@ -27,4 +27,8 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
 // f32 copy of the nodes with boxes rounded outward.
 void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out);
 
+// 16-bit global-grid copy of the nodes.  Returns false (out untouched) when the grid is too coarse
+// for the scene: mean surface-area inflation of the leaf boxes above `max_inflation`.
+bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, QuantGrid& grid, double max_inflation);
+
 }  // namespace rt

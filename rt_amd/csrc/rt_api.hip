@@ -495,10 +495,20 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             }
         sc->d.nodes64 = nullptr;
         sc->d.nodes32 = nullptr;
+        sc->d.nodes16 = nullptr;
+        bool use16 = false;
         if (use32) {
             std::vector<Node32> n32;
             narrow_nodes(bvh.nodes, n32);
             if ((rc = upload(sc, n32, &sc->d.nodes32))) return rc;
+            // 16-bit grid nodes for the per-lane (incoherent) traversal, when the grid is fine
+            // enough for this scene (RT_HIP_NODE_BOXES=f32 disables, =q16 forces)
+            std::vector<Node16> n16;
+            const bool force16 = nb && strcmp(nb, "q16") == 0, no16 = nb && strcmp(nb, "f32") == 0;
+            if (!no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
+                if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
+                use16 = true;
+            }
         } else {
             if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
         }
@@ -521,7 +531,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.n_nodes = bvh.nodes.size();
         sc->info.bvh_depth = bvh.depth;
         sc->info.max_leaf_size = bvh.max_leaf;
-        sc->info.node_bytes = use32 ? sizeof(Node32) : sizeof(Node64);
+        sc->info.node_bytes = use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
         sc->info.tri_bytes = sizeof(TriGeom);
         sc->info.sphere_bytes = sizeof(SphGeom);
         sc->info.build_seconds = tb1 - tb0;

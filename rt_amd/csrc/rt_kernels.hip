@@ -69,7 +69,13 @@ struct Box64 {
     using Node = Node64;
     D3 o, inv;
     __device__ __forceinline__ void init(D3 o_, D3 d) { o = o_; inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
-    static __device__ __forceinline__ const Node* nodes(const DScene& S) { return S.nodes64; }
+    using Scalar = double;
+    __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, double* lo_l, double* hi_l, double* lo_r, double* hi_r,
+                                          uint32_t& cl, uint32_t& cr) const {
+        const Node64* nd = &S.nodes64[cur];
+        for (int k = 0; k < 3; ++k) { lo_l[k] = nd->lo_l[k]; hi_l[k] = nd->hi_l[k]; lo_r[k] = nd->lo_r[k]; hi_r[k] = nd->hi_r[k]; }
+        cl = nd->left; cr = nd->right;
+    }
     __device__ __forceinline__ bool test(const double* lo, const double* hi, double t_min, double best, double& t_near) const {
         double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
         double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
@@ -102,7 +108,13 @@ struct Box32 {
         cy = fmaf(fabsf(oy * iy), 0x1.0p-23f, 1e-30f);
         cz = fmaf(fabsf(oz * iz), 0x1.0p-23f, 1e-30f);
     }
-    static __device__ __forceinline__ const Node* nodes(const DScene& S) { return S.nodes32; }
+    using Scalar = float;
+    __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, float* lo_l, float* hi_l, float* lo_r, float* hi_r,
+                                          uint32_t& cl, uint32_t& cr) const {
+        const Node32* nd = &S.nodes32[cur];
+        for (int k = 0; k < 3; ++k) { lo_l[k] = nd->lo_l[k]; hi_l[k] = nd->hi_l[k]; lo_r[k] = nd->lo_r[k]; hi_r[k] = nd->hi_r[k]; }
+        cl = nd->left; cr = nd->right;
+    }
     __device__ __forceinline__ bool test(const float* lo, const float* hi, double t_min, double best, float& t_near) const {
         const float r = 0x1.0p-22f;
         float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
@@ -118,6 +130,25 @@ struct Box32 {
         float tf = fminf(fminf(fx, fy), fz);
         t_near = tn;
         return !(tn > tf) && !((double)tf < t_min) && !((double)tn > best);
+    }
+};
+
+// Box16: the Box32 test on nodes quantised to the global 16-bit grid (Node16): half the bytes per
+// lane per step.  The decoded bound fmaf(q, cell, origin) is an f32 number that the builder checked
+// to enclose the f32 bound, so Box32's error budget applies unchanged.
+struct Box16 : Box32 {
+    using Node = Node16;
+    __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, float* lo_l, float* hi_l, float* lo_r, float* hi_r,
+                                          uint32_t& cl, uint32_t& cr) const {
+        const uint4* p = reinterpret_cast<const uint4*>(&S.nodes16[cur]);
+        const uint4 a = p[0], b = p[1];
+        const float ox_ = S.grid.origin[0], oy_ = S.grid.origin[1], oz_ = S.grid.origin[2];
+        const float sx = S.grid.cell[0], sy = S.grid.cell[1], sz = S.grid.cell[2];
+        lo_l[0] = fmaf((float)(a.x & 0xFFFFu), sx, ox_); lo_l[1] = fmaf((float)(a.x >> 16), sy, oy_); lo_l[2] = fmaf((float)(a.y & 0xFFFFu), sz, oz_);
+        hi_l[0] = fmaf((float)(a.y >> 16), sx, ox_);     hi_l[1] = fmaf((float)(a.z & 0xFFFFu), sy, oy_); hi_l[2] = fmaf((float)(a.z >> 16), sz, oz_);
+        lo_r[0] = fmaf((float)(a.w & 0xFFFFu), sx, ox_); lo_r[1] = fmaf((float)(a.w >> 16), sy, oy_);     lo_r[2] = fmaf((float)(b.x & 0xFFFFu), sz, oz_);
+        hi_r[0] = fmaf((float)(b.x >> 16), sx, ox_);     hi_r[1] = fmaf((float)(b.y & 0xFFFFu), sy, oy_); hi_r[2] = fmaf((float)(b.y >> 16), sz, oz_);
+        cl = b.z; cr = b.w;
     }
 };
 
@@ -142,7 +173,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
     }
     BoxT rb;
     rb.init(o, d);
-    const typename BoxT::Node* nodes = BoxT::nodes(S);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t cur = active ? S.root : REF_EMPTY;
@@ -153,12 +183,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
     // here: leaves are small and the f32 node step is cheap, so the extra idling costs more than it saves.)
     while (cur != REF_EMPTY) {
         if (!(cur & REF_LEAF)) {
-            const typename BoxT::Node* nd = &nodes[cur];
+            typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
+            uint32_t cl, cr;
+            rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
             if (STATS) ++n_nodes;
-            const uint32_t cl = nd->left, cr = nd->right;
-            decltype(nd->lo_l[0] + 0) tl = 0, tr = 0;
-            bool hl = rb.test(nd->lo_l, nd->hi_l, t_min, best, tl);
-            bool hr = cr != REF_EMPTY && rb.test(nd->lo_r, nd->hi_r, t_min, best, tr);
+            bool hl = rb.test(lo_l, hi_l, t_min, best, tl);
+            bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, t_min, best, tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
                 stack[sp++][tid] = left_first ? cr : cl;
@@ -556,7 +586,9 @@ void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
     if (!qm.lprefix[NSHARD]) return;
-    if (S.nodes32)
+    if (S.nodes16)
+        launch_trace_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.nodes32)
         launch_trace_t<Box32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else
         launch_trace_t<Box64>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);

@@ -38,6 +38,21 @@ struct alignas(64) Node32 {
 };
 static_assert(sizeof(Node32) == 64, "Node32 layout");
 
+// BVH2 node with child boxes quantised (outward) to a global 16-bit grid over the scene bounds:
+// 32 bytes, four per line.  Decoded as fmaf(q, cell, origin) in f32; the builder verifies that
+// every decoded bound encloses the f32 bound it replaces.  Used for incoherent rays, whose
+// per-lane node fetches are bound by the vector-memory address unit (bytes per lane per step).
+struct alignas(32) Node16 {
+    uint16_t lo_l[3], hi_l[3];
+    uint16_t lo_r[3], hi_r[3];
+    uint32_t left, right;
+};
+static_assert(sizeof(Node16) == 32, "Node16 layout");
+struct QuantGrid {
+    float origin[3];
+    float cell[3];
+};
+
 // Triangle geometry in leaf order: a, e1 = b - a, e2 = c - a (src/hittable.rs:412-413), f64.
 struct alignas(16) TriGeom {
     double a[3], e1[3], e2[3];
@@ -86,6 +101,7 @@ static_assert(sizeof(ShadeMat) == 64, "ShadeMat layout");
 struct DScene {
     const Node64* nodes64;
     const Node32* nodes32;
+    const Node16* nodes16;       // optional (null when quantisation would inflate the leaves too much)
     const TriGeom* tris;
     const SphGeom* sphs;
     const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres
@@ -96,6 +112,8 @@ struct DScene {
     uint32_t n_spheres, n_prims;
     uint32_t root;               // REF_EMPTY for an empty scene, else 0
     uint32_t bvh_depth;          // deepest child reference = traversal stack entries needed
+    QuantGrid grid;              // of nodes16
+    uint32_t _pad2[2];
     rt_sky sky;
 };
 

@@ -250,22 +250,39 @@ def test_exact_ties_keep_t_bit_exact(cover, oracle):
     assert (g["prim"] >= len(desc.spheres)).all()
 
 
-def test_f32_and_f64_node_boxes_agree(monkeypatch, oracle):
-    """RT_HIP_NODE_BOXES=f64 selects exact f64 boxes; the default conservative f32 boxes must give
-    the same hits and the same image, bit for bit (boxes only cull)."""
+def test_node_formats_agree(monkeypatch, oracle):
+    """RT_HIP_NODE_BOXES selects exact f64 boxes, conservative f32 boxes, or f32 boxes quantised to a
+    16-bit grid (default for the per-lane traversal when the grid is fine enough).  Boxes only cull:
+    all formats must give the same hits and the same image, bit for bit."""
     desc = scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40)
-    w32 = World.build(desc)
-    monkeypatch.setenv("RT_HIP_NODE_BOXES", "f64")
-    w64 = World.build(desc)
+    worlds = {}
+    for fmt in ("q16", "f32", "f64"):
+        monkeypatch.setenv("RT_HIP_NODE_BOXES", fmt)
+        worlds[fmt] = World.build(desc)
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
-    assert w32.info()["node_bytes"] == 64 and w64.info()["node_bytes"] == 128
+    assert [worlds[f].info()["node_bytes"] for f in ("q16", "f32", "f64")] == [32, 64, 128]
     rays = np.concatenate([random_rays(40_000, 17), degenerate_rays(desc, 6)])
-    h32, h64 = w32.hit(rays), w64.hit(rays)
-    assert_hits_equal(h32, h64)
-    assert_hits_equal(h32, oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
-    # on ordinary rays the wider f32 margins accept (almost) no extra boxes
-    _, s32 = w32.hit(rays[:40_000], with_stats=True)
-    _, s64 = w64.hit(rays[:40_000], with_stats=True)
-    assert int(s64["nodes_visited"]) <= int(s32["nodes_visited"]) <= int(s64["nodes_visited"]) * 1.01
+    hits = {f: w.hit(rays) for f, w in worlds.items()}
+    assert_hits_equal(hits["f32"], hits["f64"])
+    assert_hits_equal(hits["q16"], hits["f64"])
+    assert_hits_equal(hits["q16"], oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
+    # on ordinary rays the wider margins / coarser boxes accept only a few extra nodes
+    nv = {f: int(w.hit(rays[:40_000], with_stats=True)[1]["nodes_visited"]) for f, w in worlds.items()}
+    assert nv["f64"] <= nv["f32"] <= nv["f64"] * 1.01 and nv["f32"] <= nv["q16"] <= nv["f32"] * 1.10
     cam = Camera.new((9.0, -7.0, 4.0), (0.0, 0.0, 0.8), (0.0, 0.0, 1.0), 10.0, 0.3, 96, 64, 4, 12, 35.0)
-    assert np.array_equal(cam.render_image(w32, spp=3, seed=2), cam.render_image(w64, spp=3, seed=2))
+    img = cam.render_image(worlds["f64"], spp=3, seed=2)
+    assert np.array_equal(cam.render_image(worlds["f32"], spp=3, seed=2), img)
+    assert np.array_equal(cam.render_image(worlds["q16"], spp=3, seed=2), img)
+
+
+def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypatch, cover, oracle):
+    """The cover scene's 10000-unit ground plane makes the 16-bit grid coarser than the spheres: the
+    library keeps f32 nodes there; forcing the grid must still be conservative (same hits)."""
+    desc, world, orc = cover
+    assert world.info()["node_bytes"] == 64
+    monkeypatch.setenv("RT_HIP_NODE_BOXES", "q16")
+    forced = World.build(desc)
+    monkeypatch.delenv("RT_HIP_NODE_BOXES")
+    assert forced.info()["node_bytes"] == 32
+    rays = np.concatenate([random_rays(30_000, 23), degenerate_rays(desc, 8)])
+    assert_hits_equal(forced.hit(rays), orc.hit(rays, mode=oracle.BRUTE))
