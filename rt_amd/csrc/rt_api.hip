@@ -257,11 +257,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         uint32_t n = (uint32_t)(npix * nl);
         pp.pass_base = base;
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_raygen(pp, n, w.q[0], stream);
+        QueueMap qm = queue_map_single(n);
+        launch_raygen(pp, qm, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[1], stream));
         st.launches++;
         int cur = 0;
-        QueueMap qm = queue_map_single(n);
         for (uint32_t depth = 0; depth <= cam->max_depth && n > 0; ++depth) {
             // the survivors' counters (one per output shard), zeroed on the stream before every use
             uint32_t* d_count = w.counters + (COUNTER_BYTES / 4) * (depth & 1u);
@@ -586,11 +586,12 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     for (size_t off = 0; off < n; off += chunk) {
         const uint32_t m = (uint32_t)std::min(chunk, n - off);
         HIPCHK(hipMemcpyAsync(d_rays, rays + off, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
-        launch_prepare_rays(d_rays, m, w.q[0], stream);
+        const QueueMap qm = queue_map_single(m);
+        launch_prepare_rays(d_rays, qm, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_trace(sc->d, w.q[0], queue_map_single(m), t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
+        launch_trace(sc->d, w.q[0], qm, t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
         HIPCHK(hipEventRecord(w.ev[1], stream));
-        launch_pack_hits(w.hb, m, d_hits, stream);
+        launch_pack_hits(w.hb, qm, d_hits, stream);
         HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipGetLastError());
@@ -641,12 +642,13 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.jitter = jitter ? 1 : 0;
     pp.tiled = 0;
     hipStream_t stream = nullptr;
-    launch_raygen(pp, (uint32_t)npix, w.q[0], stream);
-    launch_trace(sc->d, w.q[0], queue_map_single((uint32_t)npix), cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
-    launch_pack_hits(w.hb, (uint32_t)npix, d_hits, stream);
+    const QueueMap qm = queue_map_single((uint32_t)npix);
+    launch_raygen(pp, qm, w.q[0], stream);
+    launch_trace(sc->d, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
+    launch_pack_hits(w.hb, qm, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {
-        launch_pack_rays(w.q[0], (uint32_t)npix, d_rays, stream);
+        launch_pack_rays(w.q[0], qm, d_rays, stream);
         HIPCHK(hipMemcpyAsync(rays_out, d_rays, npix * sizeof(rt_ray), hipMemcpyDeviceToHost, stream));
     }
     HIPCHK(hipStreamSynchronize(stream));

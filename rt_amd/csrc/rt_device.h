@@ -101,18 +101,13 @@ __device__ __forceinline__ uint32_t slot_to_pixel(uint32_t slot, uint32_t W, uin
 }
 
 // ---- sharded queue addressing ----------------------------------------------------------------
-// wave_first: logical index of the wave's lane 0 (multiple of 64, wave-uniform).  Returns whether
-// this lane holds a live entry and its physical slot.
-__device__ __forceinline__ bool queue_slot(const QueueMap& m, uint32_t wave_first, uint32_t lane, uint32_t& slot) {
-    uint32_t lo = 0, hi = NSHARD;                 // largest k with lprefix[k] <= wave_first
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {              // log2(NSHARD)
-        const uint32_t mid = (lo + hi) >> 1;
-        if (m.lprefix[mid] <= wave_first) lo = mid; else hi = mid;
-    }
-    const uint32_t off = wave_first - m.lprefix[lo] + lane;
-    slot = m.base[lo] + off;
-    return wave_first < m.lprefix[NSHARD] && off < m.count[lo];
+// wave: logical wave index (wave-uniform).  Returns whether this lane holds a live entry and its
+// physical slot.
+__device__ __forceinline__ bool queue_slot(const QueueMap& m, uint32_t wave, uint32_t lane, uint32_t& slot) {
+    const uint32_t shard = wave & (NSHARD - 1);
+    const uint32_t off = (wave / NSHARD) * 64u + lane;
+    slot = m.base[shard] + off;
+    return wave < m.n_waves && off < m.count[shard];
 }
 
 // ---- primitives -----------------------------------------------------------------------------

@@ -19,9 +19,9 @@ struct PassParams {
 };
 
 // K0: primary rays for path ids [0, n_paths) -> queue
-void launch_raygen(const PassParams& pp, uint32_t n_paths, RayQueue q, hipStream_t s);
+void launch_raygen(const PassParams& pp, const QueueMap& qm, RayQueue q, hipStream_t s);
 // World::hit input for rt_trace_closest: normalise host rays into a queue (Ray::new)
-void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t s);
+void launch_prepare_rays(const rt_ray* rays, const QueueMap& qm, RayQueue q, hipStream_t s);
 // K1: closest hit for queue[0, n)
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
                   bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
@@ -44,7 +44,7 @@ void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint
 // K5b: mean = sum / total_spp
 void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
 // hits (SoA) -> rt_hit[]; slot i holds path id pid[i] (identity for prepare_rays / first trace)
-void launch_pack_hits(HitBuf hb, uint32_t n, rt_hit* out, hipStream_t s);
-void launch_pack_rays(RayQueue q, uint32_t n, rt_ray* out, hipStream_t s);
+void launch_pack_hits(HitBuf hb, const QueueMap& qm, rt_hit* out, hipStream_t s);
+void launch_pack_rays(RayQueue q, const QueueMap& qm, rt_ray* out, hipStream_t s);
 
 }  // namespace rt

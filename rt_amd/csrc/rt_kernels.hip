@@ -18,9 +18,10 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // K0 — primary rays
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, uint32_t n_paths, RayQueue q) {
-    uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;
-    if (pid >= n_paths) return;
+__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, RayQueue q) {
+    const uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;       // logical entry = path id
+    uint32_t slot = 0;
+    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(pid >> 6), threadIdx.x & 63u, slot)) return;
     uint32_t local = pid / pp.n_pixels;
     uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
     uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
@@ -42,20 +43,19 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, uint32_t n_path
         origin = add(add(center, scale(ld3(pp.cam.defocus_u), v.x)), scale(ld3(pp.cam.defocus_v), v.y));
     }
     D3 dir = normalize(sub(ps, origin));                 // Ray::new normalises
-    q.o[0][pid] = origin.x; q.o[1][pid] = origin.y; q.o[2][pid] = origin.z;
-    q.d[0][pid] = dir.x; q.d[1][pid] = dir.y; q.d[2][pid] = dir.z;
-    q.thr[0][pid] = 1.0; q.thr[1][pid] = 1.0; q.thr[2][pid] = 1.0;
-    q.pid[pid] = pid;
+    q.o[0][slot] = origin.x; q.o[1][slot] = origin.y; q.o[2][slot] = origin.z;
+    q.d[0][slot] = dir.x; q.d[1][slot] = dir.y; q.d[2][slot] = dir.z;
+    q.pid[slot] = pid;                                   // (throughput starts at 1: k_shade does not read it at depth 0)
 }
 
-__global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    D3 o = ld3(rays[i].o), d = normalize(ld3(rays[i].d));
+__global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, QueueMap qm, RayQueue q) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = 0;
+    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
+    D3 o = ld3(rays[p].o), d = normalize(ld3(rays[p].d));
     q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
     q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
-    q.thr[0][i] = 1.0; q.thr[1][i] = 1.0; q.thr[2][i] = 1.0;
-    q.pid[i] = i;
+    q.pid[i] = p;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
     __shared__ uint32_t stack[STACK][TRACE_BLOCK];
     const uint32_t tid = threadIdx.x;
     uint32_t i = 0;
-    const bool active = queue_slot(qm, blockIdx.x * TRACE_BLOCK, tid, i);
+    const bool active = queue_slot(qm, blockIdx.x, tid, i);
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
         o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, RayQueue
     __shared__ PacketEntry stack[BVH_MAX_DEPTH];
     const uint32_t lane = threadIdx.x;
     uint32_t i = 0;
-    const bool active = queue_slot(qm, blockIdx.x * TRACE_BLOCK, lane, i);
+    const bool active = queue_slot(qm, blockIdx.x, lane, i);
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
         o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
@@ -375,9 +375,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
                                                  HitBuf hb, RayQueue qo, ShardBases ob, uint32_t* out_counts,
                                                  double* path_radiance) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_first = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) & ~63u);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
     uint32_t i = 0;
-    const bool active = queue_slot(qm, wave_first, lane, i);
+    const bool active = queue_slot(qm, wave, lane, i);
     bool alive = false;
     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
     uint32_t pid = 0;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
     // shard (counters sit 128 B apart)
     const unsigned long long mask = __ballot(alive);
     if (mask) {
-        const uint32_t shard = (wave_first >> 6) & (NSHARD - 1);
+        const uint32_t shard = wave & (NSHARD - 1);
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(out_counts + 32 * shard, (uint32_t)__popcll(mask));
         base = __shfl(base, 0) + ob.base[shard];
@@ -520,19 +520,21 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* me
     if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, uint32_t n, rt_hit* out) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, QueueMap qm, rt_hit* out) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = 0;
+    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
     rt_hit h;
     h.t = hb.t[i]; h.prim = hb.prim[i]; h._pad = 0;
-    out[i] = h;
+    out[p] = h;
 }
-__global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, uint32_t n, rt_ray* out) {
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, QueueMap qm, rt_ray* out) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t i = 0;
+    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
     rt_ray r;
     for (int k = 0; k < 3; ++k) { r.o[k] = q.o[k][i]; r.d[k] = q.d[k][i]; }
-    out[i] = r;
+    out[p] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,18 +542,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, uint32_t n, rt_
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-void launch_raygen(const PassParams& pp, uint32_t n_paths, RayQueue q, hipStream_t s) {
-    if (!n_paths) return;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_paths)), dim3(BLOCK), 0, s, pp, n_paths, q);
+void launch_raygen(const PassParams& pp, const QueueMap& qm, RayQueue q, hipStream_t s) {
+    if (!qm.n_waves) return;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, pp, qm, q);
 }
-void launch_prepare_rays(const rt_ray* rays, uint32_t n, RayQueue q, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, rays, n, q);
+void launch_prepare_rays(const rt_ray* rays, const QueueMap& qm, RayQueue q, hipStream_t s) {
+    if (!qm.n_waves) return;
+    hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, rays, qm, q);
 }
 template <class BoxT, int STACK>
 static void launch_trace_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                            unsigned long long* d_counters, hipStream_t s) {
-    const dim3 grid(qm.lprefix[NSHARD] / TRACE_BLOCK), block(TRACE_BLOCK);
+    const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
     if (stats)
         hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
     else
@@ -571,12 +573,12 @@ static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, doub
 }
 void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                          unsigned long long* d_counters, hipStream_t s) {
-    if (!qm.lprefix[NSHARD]) return;
+    if (!qm.n_waves) return;
     if (!S.nodes32) {       // f64-box scenes have no packet variant
         launch_trace(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
         return;
     }
-    const dim3 grid(qm.lprefix[NSHARD] / TRACE_BLOCK), block(TRACE_BLOCK);
+    const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
     if (stats)
         hipLaunchKernelGGL((k_trace_packet<true>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
     else
@@ -585,7 +587,7 @@ void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double
 
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
-    if (!qm.lprefix[NSHARD]) return;
+    if (!qm.n_waves) return;
     if (S.nodes16)
         launch_trace_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else if (S.nodes32)
@@ -594,19 +596,37 @@ void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min,
         launch_trace_t<Box64>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }
 
+static void finish_map(QueueMap& m) {
+    uint32_t mx = 0;
+    for (int k = 0; k < NSHARD; ++k) mx = std::max(mx, (m.count[k] + 63u) / 64u);
+    m.n_waves = mx * NSHARD;
+    m._pad[0] = m._pad[1] = m._pad[2] = 0;
+}
+
+// The map of a queue of n entries written by k_raygen / k_prepare_rays: logical entry p belongs to
+// logical wave p / 64, which lives in shard (p / 64) % NSHARD like every other queue, so the same
+// queue_slot() addressing serves producers and consumers of all queues.
 QueueMap queue_map_single(uint32_t n) {
     QueueMap m;
-    const uint32_t padded = (n + 63u) & ~63u;
-    for (int k = 0; k < NSHARD; ++k) { m.lprefix[k] = k ? padded : 0; m.base[k] = 0; m.count[k] = 0; }
-    m.lprefix[NSHARD] = padded;
-    m.count[0] = n;
+    const uint32_t nw = (n + 63u) / 64u;                       // logical waves
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < (uint32_t)NSHARD; ++k) {
+        const uint32_t wk = nw > k ? (nw - k + NSHARD - 1) / NSHARD : 0u;   // waves of shard k
+        m.base[k] = acc;
+        // entries: all waves of the shard are full except the globally last wave
+        uint32_t cnt = wk * 64u;
+        if (wk && (nw - 1) % NSHARD == k) cnt -= nw * 64u - n;
+        m.count[k] = cnt;
+        acc += wk * 64u;
+    }
+    finish_map(m);
     return m;
 }
 
 ShardBases shard_bases_for(const QueueMap& in) {
     // output shard k receives the survivors of the input waves w with w % NSHARD == k
     ShardBases b;
-    const uint32_t nw = in.lprefix[NSHARD] / 64;
+    const uint32_t nw = in.n_waves;
     uint32_t acc = 0;
     for (uint32_t k = 0; k < (uint32_t)NSHARD; ++k) {
         b.base[k] = acc;
@@ -617,23 +637,21 @@ ShardBases shard_bases_for(const QueueMap& in) {
 
 QueueMap queue_map_from_counts(const ShardBases& bases, const uint32_t* counts /* stride 32 */, uint32_t* total) {
     QueueMap m;
-    uint32_t l = 0, t = 0;
+    uint32_t t = 0;
     for (int k = 0; k < NSHARD; ++k) {
-        const uint32_t c = counts[32 * k];
-        m.lprefix[k] = l;
         m.base[k] = bases.base[k];
-        m.count[k] = c;
-        l += (c + 63u) & ~63u;
-        t += c;
+        m.count[k] = counts[32 * k];
+        t += m.count[k];
     }
-    m.lprefix[NSHARD] = l;
+    finish_map(m);
     *total = t;
     return m;
 }
+
 void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueMap& qm, HitBuf hb,
                   RayQueue q_out, const ShardBases& out_bases, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s) {
-    if (!qm.lprefix[NSHARD]) return;
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(qm.lprefix[NSHARD])), dim3(BLOCK), 0, s, S, pp, depth, q_in, qm, hb, q_out,
+    if (!qm.n_waves) return;
+    hipLaunchKernelGGL(k_shade, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qm, hb, q_out,
                        out_bases, d_out_counts, d_path_radiance);
 }
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
@@ -646,13 +664,13 @@ void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_
     if (!n) return;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
 }
-void launch_pack_hits(HitBuf hb, uint32_t n, rt_hit* out, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_pack_hits, dim3(grid_for(n)), dim3(BLOCK), 0, s, hb, n, out);
+void launch_pack_hits(HitBuf hb, const QueueMap& qm, rt_hit* out, hipStream_t s) {
+    if (!qm.n_waves) return;
+    hipLaunchKernelGGL(k_pack_hits, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, hb, qm, out);
 }
-void launch_pack_rays(RayQueue q, uint32_t n, rt_ray* out, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(BLOCK), 0, s, q, n, out);
+void launch_pack_rays(RayQueue q, const QueueMap& qm, rt_ray* out, hipStream_t s) {
+    if (!qm.n_waves) return;
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, q, qm, out);
 }
 
 }  // namespace rt

@@ -126,13 +126,16 @@ struct RayQueue {
 };
 // A ray queue is stored as NSHARD independently appended segments so that compaction spreads its
 // (returning) atomics over NSHARD counters: one counter saturates at ~88 appends/us on MI355X, which
-// at one append per wave cost more than the shading itself.  Logical indices are padded so that a
-// wave (64 consecutive logical indices) never straddles two shards.
+// at one append per wave cost more than the shading itself.  Producer wave w appends to shard
+// w % NSHARD; consumer wave b reads shard b % NSHARD at offset 64*(b / NSHARD), which interleaves
+// the shards back into (roughly) the producer's order — camera tiles stay neighbours in flight, so
+// the next bounce still sweeps the scene once instead of NSHARD times.
 constexpr int NSHARD = 64;
 struct QueueMap {
-    uint32_t lprefix[NSHARD + 1];   // logical start of shard k (multiple of 64); [NSHARD] = logical size
     uint32_t base[NSHARD];          // first physical slot of shard k
     uint32_t count[NSHARD];         // live entries in shard k
+    uint32_t n_waves;               // logical size in waves: NSHARD * max_k ceil(count[k] / 64)
+    uint32_t _pad[3];
 };
 struct ShardBases {
     uint32_t base[NSHARD];          // first physical slot of each OUTPUT shard
