@@ -179,10 +179,21 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
     int sp = 0;
     uint32_t n_nodes = 0, n_prims = 0;
 
-    // (A while-while split — descend to a leaf first, intersect leaves together — measured 13 % slower
-    // here: leaves are small and the f32 node step is cheap, so the extra idling costs more than it saves.)
-    while (cur != REF_EMPTY) {
-        if (!(cur & REF_LEAF)) {
+    // Leaf work (f64 primitive tests) is several times the cost of a node step, and in a plain
+    // per-lane if/else loop it would run on almost every iteration for a handful of lanes.  Lanes
+    // that reach a leaf therefore wait until LEAF_BATCH lanes hold one (or no lane can descend any
+    // further); only then the wave intersects leaves.  (LEAF_BATCH = 1 is the plain loop, 64 the
+    // classic while-while, which idles too long here.)
+#ifndef RT_LEAF_T
+#define RT_LEAF_T 1
+#endif
+    constexpr int LEAF_BATCH = RT_LEAF_T;
+    for (;;) {
+        const bool at_node = !(cur & REF_LEAF);                 // REF_EMPTY has the leaf bit set
+        const bool at_leaf = !at_node && cur != REF_EMPTY;
+        const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(at_leaf);
+        if (!(m_node | m_leaf)) break;
+        if (at_node) {
             typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
             uint32_t cl, cr;
             rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
@@ -200,7 +211,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
             } else {
                 cur = sp ? stack[--sp][tid] : REF_EMPTY;
             }
-        } else {
+        }
+        if (at_leaf && (__popcll(m_leaf) >= LEAF_BATCH || !m_node)) {
             const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
             if (STATS) n_prims += count;
             if (cur & REF_SPHERE) {
