@@ -111,7 +111,9 @@ struct rt_scene {
     std::vector<void*> allocs;
     rt_scene_info info{};
     std::mutex mu;
-    Workspace ws;
+    Workspace ws[2];                 // one per in-flight pass (two passes are pipelined)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_acc[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -125,8 +127,8 @@ void free_workspace(Workspace& w) {
     w = Workspace();
 }
 
-int ensure_workspace(rt_scene* sc, size_t paths) {
-    Workspace& w = sc->ws;
+int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
+    Workspace& w = sc->ws[which];
     if (!w.h_count) {
         HIPCHK(hipHostMalloc((void**)&w.h_count, COUNTER_BYTES, hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&w.h_stat, 256, hipHostMallocDefault));
@@ -234,89 +236,171 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
     const uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
-    int rc = ensure_workspace(sc, npix * per_pass);
-    if (rc) return rc;
-    Workspace& w = sc->ws;
+    const uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
+    // Two passes are kept in flight on two streams: the tail of a pass (a dozen launches over a few
+    // thousand surviving paths, each as long as its slowest ray) and the per-bounce host round trip
+    // hide behind the other pass's bulk work.  RT_HIP_PIPES=1 disables the overlap.
+    const char* pe = getenv("RT_HIP_PIPES");
+    const int n_pipes = (n_passes > 1 && !(pe && atoi(pe) == 1)) ? 2 : 1;
+    int rc;
+    for (int k = 0; k < n_pipes; ++k)
+        if ((rc = ensure_workspace(sc, npix * per_pass, k))) return rc;
+    if (n_pipes > 1 && !sc->aux_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+        for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
 
-    PassParams pp;
-    pp.cam = *cam;
-    pp.seed = opts->seed;
-    pp.n_pixels = (uint32_t)npix;
-    pp.sample_offset = opts->sample_offset;
-    pp.sample_stride = stride;
-    pp.jitter = 1;
-    pp.tiled = 1;
+    PassParams pp0;
+    pp0.cam = *cam;
+    pp0.seed = opts->seed;
+    pp0.n_pixels = (uint32_t)npix;
+    pp0.sample_offset = opts->sample_offset;
+    pp0.sample_stride = stride;
+    pp0.pass_base = 0;
+    pp0.jitter = 1;
+    pp0.tiled = 1;
 
     rt_stats st;
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
-    if (want_stats) HIPCHK(hipMemsetAsync(w.stat_counters, 0, 256, stream));
-    const double t0 = now_s();
-    for (uint32_t base = 0; base < opts->spp; base += per_pass) {
-        const uint32_t nl = std::min(per_pass, opts->spp - base);
-        uint32_t n = (uint32_t)(npix * nl);
-        pp.pass_base = base;
-        HIPCHK(hipEventRecord(w.ev[0], stream));
-        QueueMap qm = queue_map_single(n);
-        launch_raygen(pp, qm, w.q[0], stream);
-        HIPCHK(hipEventRecord(w.ev[1], stream));
-        st.launches++;
+    const bool use_packet = !getenv("RT_HIP_NO_PACKET");
+
+    struct Pipe {
+        Workspace* w = nullptr;
+        hipStream_t s = nullptr;
+        PassParams pp;
+        QueueMap qm;
+        ShardBases ob;
+        uint32_t pass = 0, nl = 0, n = 0, depth = 0;
         int cur = 0;
-        for (uint32_t depth = 0; depth <= cam->max_depth && n > 0; ++depth) {
-            // the survivors' counters (one per output shard), zeroed on the stream before every use
-            uint32_t* d_count = w.counters + (COUNTER_BYTES / 4) * (depth & 1u);
-            const ShardBases ob = shard_bases_for(qm);
-            HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, stream));
-            HIPCHK(hipEventRecord(w.ev[2], stream));
-            if (depth == 0 && !getenv("RT_HIP_NO_PACKET"))   // camera rays of 8x8 tiles: coherent
-                launch_trace_packet(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
-            else
-                launch_trace(sc->d, w.q[cur], qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, stream);
-            HIPCHK(hipEventRecord(w.ev[3], stream));
-            launch_shade(sc->d, pp, depth, w.q[cur], qm, w.hb, w.q[cur ^ 1], ob, d_count, w.path_radiance, stream);
-            HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipEventRecord(w.ev[4], stream));
-            HIPCHK(hipStreamSynchronize(stream));
+        enum { IDLE, RUNNING, WAIT_ACC } state = IDLE;
+    } pipes[2];
+    pipes[0].w = &sc->ws[0];
+    pipes[0].s = stream;
+    pipes[1].w = &sc->ws[1];
+    pipes[1].s = sc->aux_stream;
+    if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
+        HIPCHK(hipEventRecord(sc->ev_fork, stream));
+        HIPCHK(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
+    }
+    for (int k = 0; k < n_pipes; ++k)
+        if (want_stats) HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, 256, pipes[k].s));
+
+    uint32_t next_pass = 0, next_acc = 0, done_passes = 0;
+    int last_acc_pipe = -1;
+    const double t0 = now_s();
+
+    // one bounce of pipe P: zero counters, trace, shade (+compaction), read back the shard counts
+    auto submit = [&](Pipe& P) -> int {
+        Workspace& w = *P.w;
+        uint32_t* d_count = w.counters + (COUNTER_BYTES / 4) * (P.depth & 1u);
+        P.ob = shard_bases_for(P.qm);
+        HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, P.s));
+        HIPCHK(hipEventRecord(w.ev[2], P.s));
+        if (P.depth == 0 && use_packet)   // camera rays of 8x8 tiles: coherent
+            launch_trace_packet(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
+        else
+            launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
+        HIPCHK(hipEventRecord(w.ev[3], P.s));
+        launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], P.qm, w.hb, w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance, P.s);
+        HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
+        HIPCHK(hipEventRecord(w.ev[4], P.s));
+        return RT_OK;
+    };
+    auto start_pass = [&](Pipe& P) -> int {
+        P.pass = next_pass++;
+        const uint32_t base = P.pass * per_pass;
+        P.nl = std::min(per_pass, opts->spp - base);
+        P.n = (uint32_t)(npix * P.nl);
+        P.pp = pp0;
+        P.pp.pass_base = base;
+        P.depth = 0;
+        P.cur = 0;
+        P.qm = queue_map_single(P.n);
+        HIPCHK(hipEventRecord(P.w->ev[0], P.s));
+        launch_raygen(P.pp, P.qm, P.w->q[0], P.s);
+        HIPCHK(hipEventRecord(P.w->ev[1], P.s));
+        st.launches++;
+        P.state = Pipe::RUNNING;
+        return submit(P);
+    };
+    // radiance sums are added pass by pass in pass order (bit-reproducible), whichever pipe is first
+    auto accumulate = [&](Pipe& P, int pipe_index) -> int {
+        if (last_acc_pipe >= 0 && last_acc_pipe != pipe_index)
+            HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[last_acc_pipe], 0));
+        launch_accumulate(P.pp, P.w->path_radiance, P.nl, d_rgb_sum, P.s);
+        if (n_pipes > 1) HIPCHK(hipEventRecord(sc->ev_acc[pipe_index], P.s));
+        last_acc_pipe = pipe_index;
+        ++next_acc;
+        st.launches++;
+        st.passes++;
+        st.samples += (uint64_t)npix * P.nl;
+        ++done_passes;
+        P.state = Pipe::IDLE;
+        return RT_OK;
+    };
+
+    if ((rc = start_pass(pipes[0]))) return rc;
+    bool second_started = n_pipes < 2;
+    while (done_passes < n_passes) {
+        for (int k = 0; k < n_pipes; ++k) {
+            Pipe& P = pipes[k];
+            if (P.state == Pipe::IDLE) {
+                // the second pipe starts once the first is past its bulk, so the two stay out of phase
+                if (next_pass < n_passes && (k == 0 || second_started)) {
+                    if ((rc = start_pass(P))) return rc;
+                }
+                continue;
+            }
+            if (P.state == Pipe::WAIT_ACC) {
+                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
+                continue;
+            }
+            Workspace& w = *P.w;
+            HIPCHK(hipEventSynchronize(w.ev[4]));
             HIPCHK(hipGetLastError());
             float ms_t = 0.f, ms_s = 0.f;
             HIPCHK(hipEventElapsedTime(&ms_t, w.ev[2], w.ev[3]));
             HIPCHK(hipEventElapsedTime(&ms_s, w.ev[3], w.ev[4]));
-            if (depth == 0) {
+            if (P.depth == 0) {
                 float ms_r = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms_r, w.ev[0], w.ev[1]));
                 st.seconds_shade += ms_r * 1e-3;
+                st.seconds_trace_primary += ms_t * 1e-3;
+                st.primary_segments += P.n;
             }
             st.seconds_trace += ms_t * 1e-3;
             st.seconds_shade += ms_s * 1e-3;
-            if (depth == 0) {
-                st.seconds_trace_primary += ms_t * 1e-3;
-                st.primary_segments += n;
-            }
             st.trace_launches++;
             st.launches += 2;
-            st.ray_segments += n;
-            qm = queue_map_from_counts(ob, w.h_count, &n);
-            cur ^= 1;
+            st.ray_segments += P.n;
+            P.qm = queue_map_from_counts(P.ob, w.h_count, &P.n);
+            P.cur ^= 1;
+            P.depth++;
+            if (!second_started && (P.depth >= 2 || P.n == 0)) {
+                second_started = true;
+                if (next_pass < n_passes && (rc = start_pass(pipes[1]))) return rc;
+            }
+            if (P.n == 0 || P.depth > cam->max_depth) {
+                P.state = Pipe::WAIT_ACC;
+                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
+            } else if ((rc = submit(P))) {
+                return rc;
+            }
         }
-        HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, stream);
-        HIPCHK(hipEventRecord(w.ev[1], stream));
-        HIPCHK(hipEventSynchronize(w.ev[1]));
-        float ms_a = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms_a, w.ev[0], w.ev[1]));
-        st.seconds_shade += ms_a * 1e-3;
-        st.launches++;
-        st.passes++;
-        st.samples += (uint64_t)npix * nl;
     }
-    if (want_stats) HIPCHK(hipMemcpyAsync(w.h_stat, w.stat_counters, 16, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    for (int k = 0; k < n_pipes; ++k) {
+        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 16, hipMemcpyDeviceToHost, pipes[k].s));
+        HIPCHK(hipStreamSynchronize(pipes[k].s));
+    }
     HIPCHK(hipGetLastError());
     st.seconds_total = now_s() - t0;
-    if (want_stats) {
-        st.nodes_visited = w.h_stat[0];
-        st.prims_tested = w.h_stat[1];
-    }
+    if (want_stats)
+        for (int k = 0; k < n_pipes; ++k) {
+            st.nodes_visited += pipes[k].w->h_stat[0];
+            st.prims_tested += pipes[k].w->h_stat[1];
+        }
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -547,7 +631,12 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
 void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     if (hipSetDevice(sc->device) == hipSuccess) {
-        free_workspace(sc->ws);
+        free_workspace(sc->ws[0]);
+        free_workspace(sc->ws[1]);
+        if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
+        if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+        for (auto& e : sc->ev_acc)
+            if (e) (void)hipEventDestroy(e);
         for (void* p : sc->allocs) (void)hipFree(p);
     }
     (void)hipGetLastError();
@@ -573,7 +662,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     if (rc) return rc;
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     if ((rc = ensure_workspace(sc, chunk))) return rc;
-    Workspace& w = sc->ws;
+    Workspace& w = sc->ws[0];
     DevAllocs tmp;
     rt_ray* d_rays = nullptr;
     rt_hit* d_hits = nullptr;
@@ -626,7 +715,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     std::lock_guard<std::mutex> sl(sc->mu);
     if ((rc = select_device(sc->device))) return rc;
     if ((rc = ensure_workspace(sc, npix))) return rc;
-    Workspace& w = sc->ws;
+    Workspace& w = sc->ws[0];
     DevAllocs tmp;
     rt_hit* d_hits = nullptr;
     rt_ray* d_rays = nullptr;
