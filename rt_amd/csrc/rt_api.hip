@@ -264,7 +264,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     rt_stats st;
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
-    const bool use_packet = !getenv("RT_HIP_NO_PACKET");
+    const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
 
     struct Pipe {
         Workspace* w = nullptr;
@@ -298,8 +298,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         P.ob = shard_bases_for(P.qm);
         HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, P.s));
         HIPCHK(hipEventRecord(w.ev[2], P.s));
-        if (P.depth == 0 && use_packet)   // camera rays of 8x8 tiles: coherent
-            launch_trace_packet(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
+        if (P.depth == 0 && use_packet)   // camera rays of 8x8 tiles: coherent; generated in the kernel
+            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
         else
             launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
         HIPCHK(hipEventRecord(w.ev[3], P.s));
@@ -319,9 +319,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         P.cur = 0;
         P.qm = queue_map_single(P.n);
         HIPCHK(hipEventRecord(P.w->ev[0], P.s));
-        launch_raygen(P.pp, P.qm, P.w->q[0], P.s);
+        if (!use_packet) {
+            launch_raygen(P.pp, P.qm, P.w->q[0], P.s);
+            st.launches++;
+        }
         HIPCHK(hipEventRecord(P.w->ev[1], P.s));
-        st.launches++;
         P.state = Pipe::RUNNING;
         return submit(P);
     };

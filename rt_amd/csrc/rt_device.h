@@ -54,10 +54,6 @@ __device__ __forceinline__ double u64_to_unit(uint32_t lo, uint32_t hi) {
 struct RngKey { uint64_t seed; uint32_t pixel, sample, depth; };
 // block b holds slots 2b (words x,y) and 2b+1 (words z,w)
 __device__ __forceinline__ U4 rng_block(const RngKey& k, uint32_t block) {
-#ifdef RT_EXP_NORNG
-    U4 o; o.x = k.pixel * 2654435761u + block; o.y = k.sample * 40503u + k.depth; o.z = o.x ^ 0x9E3779B9u; o.w = o.y * 2246822519u;
-    return o;
-#endif
     return philox4x32_10(k.pixel, k.sample, k.depth, block, (uint32_t)k.seed, (uint32_t)(k.seed >> 32));
 }
 

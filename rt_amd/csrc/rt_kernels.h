@@ -26,8 +26,10 @@ void launch_prepare_rays(const rt_ray* rays, const QueueMap& qm, RayQueue q, hip
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
                   bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
 // K1p: the same for coherent waves (camera rays in 8x8 tiles): wave-level packet traversal through the scalar cache
-void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
-                         bool stats, unsigned long long* d_counters, hipStream_t s);
+// gen != NULL: the kernel generates the camera rays of that pass itself (K0 fused) and stores them in q
+bool packet_supported(const DScene& S);
+void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
+                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s);
 // sharded-queue bookkeeping (host): a dense queue of n entries; the output bases of a shade launch
 // over `in`; the map of the queue that launch produced, from its NSHARD counters (32 u32 apart)
 QueueMap queue_map_single(uint32_t n);

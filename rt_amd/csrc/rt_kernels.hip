@@ -11,6 +11,9 @@
 // summed per pixel in sample order, so a render is bit-reproducible.
 #include "rt_kernels.h"
 
+#include <algorithm>
+#include <cstring>
+
 #include "rt_device.h"
 
 namespace rt {
@@ -18,10 +21,8 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // K0 — primary rays
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, RayQueue q) {
-    const uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;       // logical entry = path id
-    uint32_t slot = 0;
-    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(pid >> 6), threadIdx.x & 63u, slot)) return;
+// Camera::get_ray for path id `pid` of the pass (src/camera.rs:231-254)
+__device__ __forceinline__ void camera_ray(const PassParams& pp, uint32_t pid, D3& origin, D3& dir) {
     uint32_t local = pid / pp.n_pixels;
     uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
     uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, Ra
     double oy = pp.jitter ? halton3(sample) : 0.0;
     D3 p00 = ld3(pp.cam.pixel00), du = ld3(pp.cam.pixel_du), dv = ld3(pp.cam.pixel_dv), center = ld3(pp.cam.center);
     D3 ps = add(add(p00, scale(du, (double)x + ox)), scale(dv, (double)y + oy));
-    D3 origin = center;
+    origin = center;
     if (pp.jitter && !(pp.cam.defocus_angle <= 0.0)) {
         // Vec3::random_in_unit_disc (src/vec3.rs:124-135); rejection k uses Philox block k of the
         // primary-ray key (depth tag 0xFFFFFFFF); capped at 32 rejections like the oracle
@@ -42,7 +43,15 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, Ra
         }
         origin = add(add(center, scale(ld3(pp.cam.defocus_u), v.x)), scale(ld3(pp.cam.defocus_v), v.y));
     }
-    D3 dir = normalize(sub(ps, origin));                 // Ray::new normalises
+    dir = normalize(sub(ps, origin));                    // Ray::new normalises
+}
+
+__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, RayQueue q) {
+    const uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;       // logical entry = path id
+    uint32_t slot = 0;
+    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(pid >> 6), threadIdx.x & 63u, slot)) return;
+    D3 origin, dir;
+    camera_ray(pp, pid, origin, dir);
     q.o[0][slot] = origin.x; q.o[1][slot] = origin.y; q.o[2][slot] = origin.z;
     q.d[0][slot] = dir.x; q.d[1][slot] = dir.y; q.d[2][slot] = dir.z;
     q.pid[slot] = pid;                                   // (throughput starts at 1: k_shade does not read it at depth 0)
@@ -273,17 +282,27 @@ __device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __hiloi
 
 struct PacketEntry { uint32_t ref, mask_lo, mask_hi; };
 
-template <bool STATS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
-                                                               HitBuf hb, unsigned long long* counters) {
+// GEN: the wave generates its own camera rays (K0 fused in: saves the queue round trip of k_raygen)
+// and stores them for k_shade.
+template <bool STATS, bool GEN>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueMap qm, double t_min,
+                                                               double t_max, HitBuf hb, unsigned long long* counters) {
     __shared__ PacketEntry stack[BVH_MAX_DEPTH];
     const uint32_t lane = threadIdx.x;
     uint32_t i = 0;
     const bool active = queue_slot(qm, blockIdx.x, lane, i);
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
-        o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
-        d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+        if (GEN) {
+            const uint32_t pid = blockIdx.x * TRACE_BLOCK + lane;
+            camera_ray(pp, pid, o, d);
+            q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
+            q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
+            q.pid[i] = pid;
+        } else {
+            o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+            d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+        }
     }
     Box32 rb;
     rb.init(o, d);
@@ -404,11 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
         if (prim == RT_MISS) {
             // Camera::raycast miss branch (src/camera.rs:308-312)
             D3 dir = normalize(d);
-#ifdef RT_EXP_NOSKY
-            L = mul(thr, mk(0.5 + 0.1 * dir.z, 0.6, 0.7));
-#else
             L = mul(thr, sky_color_toward(S.sky, dir));
-#endif
         } else {
             const double t = hb.t[i];
             SurfaceHit h;
@@ -583,18 +598,25 @@ static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, doub
     else
         launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }
-void launch_trace_packet(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                         unsigned long long* d_counters, hipStream_t s) {
+bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant
+
+void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
+                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s) {
     if (!qm.n_waves) return;
-    if (!S.nodes32) {       // f64-box scenes have no packet variant
-        launch_trace(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        return;
-    }
     const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
-    if (stats)
-        hipLaunchKernelGGL((k_trace_packet<true>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-    else
-        hipLaunchKernelGGL((k_trace_packet<false>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+    PassParams pp;
+    if (gen) pp = *gen; else memset(&pp, 0, sizeof(pp));
+    if (gen) {
+        if (stats)
+            hipLaunchKernelGGL((k_trace_packet<true, true>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
+        else
+            hipLaunchKernelGGL((k_trace_packet<false, true>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((k_trace_packet<true, false>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
+        else
+            hipLaunchKernelGGL((k_trace_packet<false, false>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
+    }
 }
 
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,

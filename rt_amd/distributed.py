@@ -42,7 +42,7 @@ def render_distributed(render_sum, out_sum, spp_per_rank, seed=0):
     out_sum.zero_()
     spp, off, stride = partition(spp_per_rank, rank, world)
     stats = render_sum(spp, off, stride, seed, out_sum)
-    if world > 1:
+    if dist.is_initialized():
         dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
     mean = out_sum / float(spp_per_rank * world) if rank == 0 else None
     return mean, stats
