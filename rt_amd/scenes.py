@@ -237,12 +237,27 @@ def icosphere(subdiv):
     return V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]      # outward-facing (counter-clockwise from outside)
 
 
+def _lattice_noise(seed, size, cell):
+    """Value noise of period-free lattice spacing `cell` sampled on a size x size pixel grid:
+    the lattice is hashed once and bilinearly interpolated (smoothstep fade)."""
+    n = size // cell + 2
+    iy, ix = np.mgrid[0:n, 0:n]
+    lat = hash_u01(seed, ix, iy)
+    t = (np.arange(size) % cell) / float(cell)
+    f = t * t * (3.0 - 2.0 * t)
+    i0 = np.arange(size) // cell
+    a = lat[i0][:, i0] * (1 - f)[None, :] + lat[i0][:, i0 + 1] * f[None, :]
+    b = lat[i0 + 1][:, i0] * (1 - f)[None, :] + lat[i0 + 1][:, i0 + 1] * f[None, :]
+    return a * (1 - f)[:, None] + b * f[:, None]
+
+
 def _noise_texture(seed, size):
-    y, x = np.mgrid[0:size, 0:size].astype(np.float64)
+    y, x = np.mgrid[0:size, 0:size]
+    h = _mix(_mix(np.asarray(seed, dtype=U64)) ^ (x.astype(U64) * U64(0xD6E8FEB86659FD93) + y.astype(U64) * U64(0x9E3779B97F4A7C15)))
     img = np.zeros((size, size, 4), dtype=np.uint8)
     for ch in range(3):
-        n = 0.5 * _value_noise(seed + ch, x / 64.0, y / 64.0) + 0.3 * _value_noise(seed + 10 + ch, x / 8.0, y / 8.0) \
-            + 0.2 * hash_u01(seed + 20 + ch, x, y)
+        grain = ((h >> U64(16 * ch)) & U64(0xFFFF)).astype(np.float64) / 65536.0
+        n = 0.5 * _lattice_noise(seed + ch, size, 64) + 0.3 * _lattice_noise(seed + 10 + ch, size, 8) + 0.2 * grain
         img[..., ch] = np.clip(np.rint(255.0 * (0.25 + 0.7 * n)), 0, 255).astype(np.uint8)
     return img
 
