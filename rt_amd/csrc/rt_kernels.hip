@@ -77,7 +77,11 @@ __global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, Queu
 struct Box64 {
     using Node = Node64;
     D3 o, inv;
-    __device__ __forceinline__ void init(D3 o_, D3 d) { o = o_; inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+    double lo_t, hi_t;     // [t_min, current nearest t]
+    __device__ __forceinline__ void init(D3 o_, D3 d, double t_min, double t_max) {
+        o = o_; inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); lo_t = t_min; hi_t = t_max;
+    }
+    __device__ __forceinline__ void nearest(double best) { hi_t = best; }
     using Scalar = double;
     __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, double* lo_l, double* hi_l, double* lo_r, double* hi_r,
                                           uint32_t& cl, uint32_t& cr) const {
@@ -85,7 +89,7 @@ struct Box64 {
         for (int k = 0; k < 3; ++k) { lo_l[k] = nd->lo_l[k]; hi_l[k] = nd->hi_l[k]; lo_r[k] = nd->lo_r[k]; hi_r[k] = nd->hi_r[k]; }
         cl = nd->left; cr = nd->right;
     }
-    __device__ __forceinline__ bool test(const double* lo, const double* hi, double t_min, double best, double& t_near) const {
+    __device__ __forceinline__ bool test(const double* lo, const double* hi, double& t_near) const {
         double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
         double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
         double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
@@ -94,7 +98,7 @@ struct Box64 {
         tn *= tn > 0.0 ? 1.0 - 1e-15 : 1.0 + 1e-15;      // (multiplying keeps +-inf; subtracting would make NaN)
         tf *= tf > 0.0 ? 1.0 + 1e-15 : 1.0 - 1e-15;
         t_near = tn;
-        return !(tn > tf) && !(tf < t_min) && !(tn > best);
+        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
     }
 };
 
@@ -110,7 +114,12 @@ struct Box64 {
 struct Box32 {
     using Node = Node32;
     float ox, oy, oz, ix, iy, iz, cx, cy, cz;
-    __device__ __forceinline__ void init(D3 o, D3 d) {
+    float lo_t, hi_t;      // f32 bracket of [t_min, current nearest t]: lo_t <= t_min, hi_t >= nearest
+    static __device__ __forceinline__ float f32_below(double x) { float f = (float)x; return f - fabsf(f) * 0x1.0p-22f; }
+    static __device__ __forceinline__ float f32_above(double x) { float f = (float)x; return f + fabsf(f) * 0x1.0p-22f; }
+    __device__ __forceinline__ void nearest(double best) { hi_t = f32_above(best); }
+    __device__ __forceinline__ void init(D3 o, D3 d, double t_min, double t_max) {
+        lo_t = f32_below(t_min); hi_t = f32_above(t_max);
         ox = (float)o.x; oy = (float)o.y; oz = (float)o.z;
         ix = (float)(1.0 / d.x); iy = (float)(1.0 / d.y); iz = (float)(1.0 / d.z);
         cx = fmaf(fabsf(ox * ix), 0x1.0p-23f, 1e-30f);
@@ -124,7 +133,7 @@ struct Box32 {
         for (int k = 0; k < 3; ++k) { lo_l[k] = nd->lo_l[k]; hi_l[k] = nd->hi_l[k]; lo_r[k] = nd->lo_r[k]; hi_r[k] = nd->hi_r[k]; }
         cl = nd->left; cr = nd->right;
     }
-    __device__ __forceinline__ bool test(const float* lo, const float* hi, double t_min, double best, float& t_near) const {
+    __device__ __forceinline__ bool test(const float* lo, const float* hi, float& t_near) const {
         const float r = 0x1.0p-22f;
         float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
         float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
@@ -138,7 +147,7 @@ struct Box32 {
         float tn = fmaxf(fmaxf(nx, ny), nz);
         float tf = fminf(fminf(fx, fy), fz);
         t_near = tn;
-        return !(tn > tf) && !((double)tf < t_min) && !((double)tn > best);
+        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
     }
 };
 
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
         d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
     }
     BoxT rb;
-    rb.init(o, d);
+    rb.init(o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t cur = active ? S.root : REF_EMPTY;
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
             uint32_t cl, cr;
             rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
             if (STATS) ++n_nodes;
-            bool hl = rb.test(lo_l, hi_l, t_min, best, tl);
-            bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, t_min, best, tr);
+            bool hl = rb.test(lo_l, hi_l, tl);
+            bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
                 stack[sp++][tid] = left_first ? cr : cl;
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
                 for (uint32_t k = 0; k < count; ++k) {
                     const SphGeom* g = &S.sphs[first + k];
                     double t;
-                    if (sph_test(ld3(g->c), g->r, ld3(g->rot2), o, d, t_min, best, t)) { best = t; prim = g->prim; }
+                    if (sph_test(ld3(g->c), g->r, ld3(g->rot2), o, d, t_min, best, t)) { best = t; prim = g->prim; rb.nearest(best); }
                 }
             } else {
                 for (uint32_t k = 0; k < count; ++k) {
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
                     double t, u, v;
                     if (tri_test(ld3(g->a), ld3(g->e1), ld3(g->e2), o, d, t_min, best, t, u, v)) {
                         best = t; prim = g->prim; bu = u; bv = v;
+                        rb.nearest(best);
                     }
                 }
             }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
         }
     }
     Box32 rb;
-    rb.init(o, d);
+    rb.init(o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0;
@@ -323,8 +333,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
             const float lo_r[3] = {__uint_as_float(nd[6]), __uint_as_float(nd[7]), __uint_as_float(nd[8])};
             const float hi_r[3] = {__uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11])};
             float tl = 0.f, tr = 0.f;
-            const bool hl = mine && rb.test(lo_l, hi_l, t_min, best, tl);
-            const bool hr = mine && cr != REF_EMPTY && rb.test(lo_r, hi_r, t_min, best, tr);
+            const bool hl = mine && rb.test(lo_l, hi_l, tl);
+            const bool hr = mine && cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
             if (STATS && mine) ++n_nodes;
             const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
             if (ml && mr) {
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
                     const double r = mkd(g[6], g[7]);
                     const D3 rot2 = mk(mkd(g[8], g[9]), mkd(g[10], g[11]), mkd(g[12], g[13]));
                     double t;
-                    if (mine && sph_test(c, r, rot2, o, d, t_min, best, t)) { best = t; prim = g[14]; }
+                    if (mine && sph_test(c, r, rot2, o, d, t_min, best, t)) { best = t; prim = g[14]; rb.nearest(best); }
                 }
             } else {
                 for (uint32_t k = 0; k < count; ++k) {
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
                     const D3 e1 = mk(mkd(g[6], g[7]), mkd(g[8], g[9]), mkd(g[10], g[11]));
                     const D3 e2 = mk(mkd(g[12], g[13]), mkd(g[14], g[15]), mkd(g2[0], g2[1]));
                     double t, u, v;
-                    if (mine && tri_test(a, e1, e2, o, d, t_min, best, t, u, v)) { best = t; prim = g2[2]; bu = u; bv = v; }
+                    if (mine && tri_test(a, e1, e2, o, d, t_min, best, t, u, v)) { best = t; prim = g2[2]; bu = u; bv = v; rb.nearest(best); }
                 }
             }
         }
