@@ -139,6 +139,8 @@ typedef struct rt_stats {
     uint64_t primary_segments;     /* camera rays (depth 0) among ray_segments                 */
     double seconds_trace_primary;  /* part of seconds_trace spent on depth-0 launches; the
                                       rest is the incoherent-bounce part                      */
+    uint64_t nodes_visited_primary; /* parts of nodes_visited / prims_tested counted by the    */
+    uint64_t prims_tested_primary;  /* depth-0 (camera ray) launches; only when collect_stats  */
 } rt_stats;
 
 typedef struct rt_ray { double o[3], d[3]; } rt_ray;   /* d need not be normalised: Ray::new does */

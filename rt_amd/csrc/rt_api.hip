@@ -21,7 +21,7 @@
 
 static_assert(sizeof(rt_sphere) == 64 && sizeof(rt_triangle) == 152 && sizeof(rt_material) == 32 &&
                   sizeof(rt_texture) == 64 && sizeof(rt_sky) == 144 && sizeof(rt_camera) == 184 &&
-                  sizeof(rt_opts) == 40 && sizeof(rt_stats) == 88 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
+                  sizeof(rt_opts) == 40 && sizeof(rt_stats) == 104 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
                   sizeof(rt_scene_info) == 64,
               "ABI struct sizes (mirrored in rt_amd/_abi.py)");
 
@@ -299,9 +299,10 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, P.s));
         HIPCHK(hipEventRecord(w.ev[2], P.s));
         if (P.depth == 0 && use_packet)   // camera rays of 8x8 tiles: coherent; generated in the kernel
-            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
+            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters + 2, P.s);
         else
-            launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters, P.s);
+            launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats,
+                         w.stat_counters + (P.depth == 0 ? 2 : 0), P.s);
         HIPCHK(hipEventRecord(w.ev[3], P.s));
         launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], P.qm, w.hb, w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance, P.s);
         HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
@@ -393,15 +394,17 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         }
     }
     for (int k = 0; k < n_pipes; ++k) {
-        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 16, hipMemcpyDeviceToHost, pipes[k].s));
+        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 32, hipMemcpyDeviceToHost, pipes[k].s));
         HIPCHK(hipStreamSynchronize(pipes[k].s));
     }
     HIPCHK(hipGetLastError());
     st.seconds_total = now_s() - t0;
     if (want_stats)
         for (int k = 0; k < n_pipes; ++k) {
-            st.nodes_visited += pipes[k].w->h_stat[0];
-            st.prims_tested += pipes[k].w->h_stat[1];
+            st.nodes_visited += pipes[k].w->h_stat[0] + pipes[k].w->h_stat[2];
+            st.prims_tested += pipes[k].w->h_stat[1] + pipes[k].w->h_stat[3];
+            st.nodes_visited_primary += pipes[k].w->h_stat[2];
+            st.prims_tested_primary += pipes[k].w->h_stat[3];
         }
     if (stats) *stats = st;
     return RT_OK;
