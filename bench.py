@@ -98,6 +98,21 @@ def cpu_baseline(desc, cam, target_seconds):
             "value_with_distance_pruning": samples / dt_prune / 1e6}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the two traversal kernels, from the newest committed PMC summary of this workload
+    (profiles/*_traffic_<workload>.json, written by tools/pmc_summary.py from separate --pmc passes; FETCH_SIZE
+    doubled for gfx950).  PMC passes cannot run inside the timed bench, so this is the committed measurement or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                          "*_traffic_%s.json" % workload.replace("_", ""))))
+    if not files:
+        return None, None, None
+    k = json.load(open(files[-1]))["kernels"]
+    pick = lambda pre: next((v["traffic_bytes_per_launch"] for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
+                             if n.startswith(pre)), None)
+    return pick("k_trace<"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1])
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +213,7 @@ def main():
         pv_n, pv_p = s_pnodes / max(1, s_pseg), s_pprims / max(1, s_pseg)
         p_bytes_per_seg = 28 + 72 + pv_n * 64 + pv_p * prim_bytes   # hit record out, generated ray out (fused raygen)
         p_achieved = prim_seg * p_bytes_per_seg / prim_s / 1e9 if prim_s > 0 else 0.0
+        traffic, p_traffic, traffic_src = pmc_traffic(args.workload)
         img = rgb_mean.cpu().numpy()
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
@@ -208,7 +224,7 @@ def main():
                        "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_trace (per-lane traversal of bounce segments)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_trace (per-lane traversal of bounce segments)",
                          "avg_launch_ms": bounce_s / max(1, bounce_launches) * 1e3, "launches": bounce_launches,
                          "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
                          "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
@@ -216,7 +232,7 @@ def main():
                          "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak; "
                                  "two passes run on two streams, so event-timed kernel durations include time shared with the other pass" % (info["device_bytes"] / 2 ** 20)},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_trace_packet (camera rays, fused raygen)",
+                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic, "kernel": "k_trace_packet (camera rays, fused raygen)",
                                 "avg_launch_ms": prim_s / max(1, n_launch - bounce_launches) * 1e3,
                                 "launches": n_launch - bounce_launches, "segments": prim_seg,
                                 "bytes_per_segment": p_bytes_per_seg, "nodes_per_segment": pv_n, "prims_per_segment": pv_p,

@@ -27,3 +27,22 @@ for k in sorted(cnt, key=lambda k: -dur.get(k, [0, 0])[1]):
     print(k)
     for c, v in sorted(cnt[k].items()):
         print(f"    {c:28s} {v:.6g}")
+# --traffic <out.json>: HBM-side bytes per launch of each kernel, FETCH_SIZE / WRITE_SIZE are reported in KiB;
+# FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B; calibrated
+# there for wide streaming reads only, so for these gather kernels it is an upper estimate of the correction).
+if len(sys.argv) > 3 and sys.argv[2] == "--traffic":
+    import json
+    n_disp = defaultdict(int)
+    for f in glob.glob(os.path.join(d, "tcc1", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "FETCH_SIZE":
+                n_disp[short(r["Kernel_Name"])] += 1
+    out = {}
+    for k, n in n_disp.items():
+        if not k.startswith("k_"):
+            continue
+        fetch = cnt[k].get("FETCH_SIZE", 0.0) * 1024.0
+        write = cnt[k].get("WRITE_SIZE", 0.0) * 1024.0
+        out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fetch / n, "write_bytes_per_launch": write / n,
+                  "traffic_bytes_per_launch": (2.0 * fetch + write) / n}
+    json.dump({"source": os.path.basename(d.rstrip("/")), "kernels": out}, open(sys.argv[3], "w"), indent=1)
