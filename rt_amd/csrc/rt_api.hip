@@ -394,7 +394,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         }
     }
     for (int k = 0; k < n_pipes; ++k) {
-        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 32, hipMemcpyDeviceToHost, pipes[k].s));
+        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 64, hipMemcpyDeviceToHost, pipes[k].s));
         HIPCHK(hipStreamSynchronize(pipes[k].s));
     }
     HIPCHK(hipGetLastError());
@@ -405,6 +405,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.prims_tested += pipes[k].w->h_stat[1] + pipes[k].w->h_stat[3];
             st.nodes_visited_primary += pipes[k].w->h_stat[2];
             st.prims_tested_primary += pipes[k].w->h_stat[3];
+            if (getenv("RT_HIP_DEBUG_UTIL")) {      // bounce launches: lane steps / (64 x wave loop iterations)
+                const unsigned long long* h = pipes[k].w->h_stat;
+                fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
+                        k, h[0], h[5], h[4], h[4] ? (double)(h[0] + h[5]) / (64.0 * (double)h[4]) : 0.0);
+            }
         }
     if (stats) *stats = st;
     return RT_OK;

@@ -301,3 +301,26 @@ def test_converged_image_relmse_at_4096_spp(cover, oracle):
     # and the estimate itself has converged: an independent seed agrees to the same criterion
     other = cam.render_image(world, spp=4096, seed=12)
     assert float(np.mean((other - ref) ** 2 / (ref ** 2 + 1e-4))) < 1e-2
+
+
+def test_persistent_refill_kernel_is_bit_exact(monkeypatch, cover, mixed, oracle):
+    """The persistent traversal kernel (finished lanes take new rays) against the oracle and against the
+    one-chunk-per-wave kernel: a few persistent waves over many ragged chunks, then a render through it."""
+    desc, world, orc = mixed
+    rays = random_rays(30_011, 77)                       # 469 chunks, the last one ragged
+    plain = world.hit(rays)
+    monkeypatch.setenv("RT_HIP_REFILL", "1")                # opt-in: slower than the plain kernel on MI355X
+    for slots in (1, 7, 64):
+        monkeypatch.setenv("RT_HIP_REFILL_SLOTS", str(slots))
+        got = world.hit(rays)
+        assert np.array_equal(got["prim"], plain["prim"]) and np.array_equal(got["t"], plain["t"])
+    assert_hits_equal(got, orc.hit(rays, mode=oracle.BRUTE))
+    desc, world, orc = cover
+    cam = scenes.cover_camera(128, 72, spp=3, max_depth=50, defocus=True)
+    monkeypatch.setenv("RT_HIP_REFILL_SLOTS", "5")
+    img, st = cam.render_image(world, spp=3, seed=12345, with_stats=True)
+    monkeypatch.setenv("RT_HIP_NO_REFILL", "1")
+    img0, st0 = cam.render_image(world, spp=3, seed=12345, with_stats=True)
+    assert np.array_equal(img, img0)
+    for k in ("ray_segments", "nodes_visited", "prims_tested"):
+        assert int(st[k]) == int(st0[k])
