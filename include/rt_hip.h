@@ -165,8 +165,8 @@ void rt_scene_destroy(rt_scene* scene);   /* NULL is a no-op */
 typedef struct rt_scene_info {
     uint64_t n_prims, n_nodes, device_bytes;
     uint32_t bvh_depth, max_leaf_size;
-    uint32_t node_bytes, tri_bytes, sphere_bytes;   /* per-record sizes of the HBM layout */
-    uint32_t _pad;
+    uint32_t node_bytes, tri_bytes, sphere_bytes;   /* per-record sizes of the HBM layout (node: the one bounce rays traverse) */
+    uint32_t bvh_width;                             /* children per node of that structure: 2 or 4 */
     double build_seconds, upload_seconds;
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);

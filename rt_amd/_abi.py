@@ -43,7 +43,7 @@ ray_dt = np.dtype([("o", "<f8", 3), ("d", "<f8", 3)])
 hit_dt = np.dtype([("t", "<f8"), ("prim", "<u4"), ("_pad", "<u4")])
 scene_info_dt = np.dtype([("n_prims", "<u8"), ("n_nodes", "<u8"), ("device_bytes", "<u8"),
                           ("bvh_depth", "<u4"), ("max_leaf_size", "<u4"), ("node_bytes", "<u4"),
-                          ("tri_bytes", "<u4"), ("sphere_bytes", "<u4"), ("_pad", "<u4"),
+                          ("tri_bytes", "<u4"), ("sphere_bytes", "<u4"), ("bvh_width", "<u4"),
                           ("build_seconds", "<f8"), ("upload_seconds", "<f8")])
 # oracle-only record (oracle/rt_oracle.h)
 isect_dt = np.dtype([("point", "<f8", 3), ("normal", "<f8", 3), ("uv", "<f8", 2), ("t", "<f8"),

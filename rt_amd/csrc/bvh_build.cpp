@@ -259,7 +259,9 @@ bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, Qua
         double cell = ((double)hi[k] - (double)lo[k]) / 65535.0 * 1.0001;
         g.cell[k] = round_up(cell > 0.0 ? cell : 1e-30);
     }
-    auto dec = [&](uint32_t q, int k) { return std::fmaf((float)q, g.cell[k], g.origin[k]); };   // == device decode
+    // the plane a kernel tests against is the REAL number origin + q*cell (rays are moved into cell units,
+    // q itself is the coordinate): 16 x 24-bit product plus a 24-bit term, exact in 64-bit-mantissa arithmetic
+    auto dec = [&](uint32_t q, int k) { return (long double)g.origin[k] + (long double)q * (long double)g.cell[k]; };
     auto qlo = [&](float v, int k, uint16_t& o) {
         double q = std::floor(((double)v - (double)g.origin[k]) / (double)g.cell[k]);
         long qi = (long)std::min(std::max(q, 0.0), 65535.0);
@@ -303,6 +305,96 @@ bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, Qua
         if (has_r && (a.right & REF_LEAF)) { double s0 = area(a.lo_r, a.hi_r, pad0); if (s0 > 0) { infl += area(a.lo_r, a.hi_r, pad1) / s0; ++n_leaf; } }
     }
     if (n_leaf && infl / (double)n_leaf > max_inflation) return false;
+    out.swap(res);
+    return true;
+}
+
+namespace {
+struct Wide {
+    const std::vector<Node64>& in;
+    const QuantGrid& g;
+    std::vector<Node4>& out;
+    bool ok = true;
+    struct Ent { uint32_t ref; double lo[3], hi[3]; };
+    long double dec(uint32_t q, int k) const { return (long double)g.origin[k] + (long double)q * (long double)g.cell[k]; }   // exact plane
+    uint16_t qlo(double x, int k) {
+        const float v = round_down(x);
+        double q = std::floor(((double)v - (double)g.origin[k]) / (double)g.cell[k]);
+        long qi = (long)std::min(std::max(q, 0.0), 65535.0);
+        while (qi > 0 && dec((uint32_t)qi, k) > v) --qi;
+        if (dec((uint32_t)qi, k) > v) ok = false;
+        return (uint16_t)qi;
+    }
+    uint16_t qhi(double x, int k) {
+        const float v = round_up(x);
+        double q = std::ceil(((double)v - (double)g.origin[k]) / (double)g.cell[k]);
+        long qi = (long)std::min(std::max(q, 0.0), 65535.0);
+        while (qi < 65535 && dec((uint32_t)qi, k) < v) ++qi;
+        if (dec((uint32_t)qi, k) < v) ok = false;
+        return (uint16_t)qi;
+    }
+    static double area(const Ent& e) {
+        const double x = e.hi[0] - e.lo[0], y = e.hi[1] - e.lo[1], z = e.hi[2] - e.lo[2];
+        return x * y + y * z + z * x;
+    }
+    static void children(const Node64& n, Ent* e, int& c) {
+        c = 0;
+        e[c].ref = n.left;
+        for (int k = 0; k < 3; ++k) { e[c].lo[k] = n.lo_l[k]; e[c].hi[k] = n.hi_l[k]; }
+        ++c;
+        if (n.right != REF_EMPTY) {
+            e[c].ref = n.right;
+            for (int k = 0; k < 3; ++k) { e[c].lo[k] = n.lo_r[k]; e[c].hi[k] = n.hi_r[k]; }
+            ++c;
+        }
+    }
+    // emits the BVH4 node that replaces BVH2 node n2; returns its stack need
+    uint32_t emit(uint32_t n2, uint32_t& index) {
+        Ent e[5];
+        int c = 0;
+        children(in[n2], e, c);
+        while (c < 4) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int i = 0; i < c; ++i)
+                if (!(e[i].ref & REF_LEAF) && area(e[i]) > best_area) { best = i; best_area = area(e[i]); }
+            if (best < 0) break;
+            Ent sub[2];
+            int cs = 0;
+            children(in[e[best].ref], sub, cs);
+            e[best] = sub[0];
+            if (cs == 2) e[c++] = sub[1];
+        }
+        index = (uint32_t)out.size();
+        out.emplace_back();
+        uint32_t refs[4] = {REF_EMPTY, REF_EMPTY, REF_EMPTY, REF_EMPTY}, deepest = 0;
+        for (int i = 0; i < c; ++i) {
+            if (e[i].ref & REF_LEAF) { refs[i] = e[i].ref; continue; }
+            uint32_t ci = 0;
+            deepest = std::max(deepest, emit(e[i].ref, ci));
+            refs[i] = ci;
+        }
+        Node4& nd = out[index];
+        for (int i = 0; i < 4; ++i) {
+            nd.child[i] = refs[i];
+            for (int k = 0; k < 3; ++k) {
+                nd.box[i][k] = i < c ? qlo(e[i].lo[k], k) : (uint16_t)65535;
+                nd.box[i][3 + k] = i < c ? qhi(e[i].hi[k], k) : (uint16_t)0;
+            }
+        }
+        return (uint32_t)(c - 1) + deepest;
+    }
+};
+}  // namespace
+
+bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<Node4>& out, uint32_t& stack_need) {
+    if (in.empty()) return false;
+    std::vector<Node4> res;
+    res.reserve(in.size() / 2 + 16);
+    Wide w{in, grid, res};
+    uint32_t root = 0;
+    stack_need = w.emit(0, root);
+    if (!w.ok || root != 0) return false;
     out.swap(res);
     return true;
 }

@@ -590,18 +590,35 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->d.nodes64 = nullptr;
         sc->d.nodes32 = nullptr;
         sc->d.nodes16 = nullptr;
-        bool use16 = false;
+        sc->d.nodes4 = nullptr;
+        sc->d.stack4 = 0;
+        bool use16 = false, use4 = false;
+        size_t n_nodes4 = 0;
         if (use32) {
             std::vector<Node32> n32;
             narrow_nodes(bvh.nodes, n32);
             if ((rc = upload(sc, n32, &sc->d.nodes32))) return rc;
             // 16-bit grid nodes for the per-lane (incoherent) traversal, when the grid is fine
-            // enough for this scene (RT_HIP_NODE_BOXES=f32 disables, =q16 forces)
+            // enough for this scene (RT_HIP_NODE_BOXES=f32 disables; =q16 forces the grid and keeps the
+            // BVH2; =w4 forces the grid and the BVH4), and on the same grid the BVH4 that bounce rays use
             std::vector<Node16> n16;
-            const bool force16 = nb && strcmp(nb, "q16") == 0, no16 = nb && strcmp(nb, "f32") == 0;
+            const bool force4 = nb && strcmp(nb, "w4") == 0;
+            const bool force16 = (nb && strcmp(nb, "q16") == 0) || force4, no16 = nb && strcmp(nb, "f32") == 0;
             if (!no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
                 if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
                 use16 = true;
+                std::vector<Node4> n4;
+                uint32_t need = 0;
+                if ((!force16 || force4) && widen_nodes(bvh.nodes, sc->d.grid, n4, need) && need <= (uint32_t)BVH4_MAX_STACK) {
+                    if ((rc = upload(sc, n4, &sc->d.nodes4))) return rc;
+                    sc->d.stack4 = need;
+                    n_nodes4 = n4.size();
+                    use4 = true;
+                }
+                if (getenv("RT_HIP_DEBUG_UTIL")) {
+                    fprintf(stderr, "[rt_hip] BVH4: %zu nodes from %zu BVH2 nodes, stack need %u, %s\n", n4.size(), bvh.nodes.size(), need,
+                            use4 ? "used" : "not used");
+                }
             }
         } else {
             if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
@@ -625,7 +642,9 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.n_nodes = bvh.nodes.size();
         sc->info.bvh_depth = bvh.depth;
         sc->info.max_leaf_size = bvh.max_leaf;
-        sc->info.node_bytes = use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
+        sc->info.node_bytes = use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
+        sc->info.bvh_width = use4 ? 4 : 2;
+        (void)n_nodes4;
         sc->info.tri_bytes = sizeof(TriGeom);
         sc->info.sphere_bytes = sizeof(SphGeom);
         sc->info.build_seconds = tb1 - tb0;

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, Queu
 // ---------------------------------------------------------------------------------------------
 // K1 — closest hit.  Per-lane traversal stack in LDS ([entry][lane]: conflict-free).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+
 // Ray-side state of the slab test, one policy per node format.
 //
 // Box64: f64 boxes.  The interval is widened by a few ulps so that a primitive touching its own
@@ -79,7 +81,7 @@ struct Box64 {
     using Node = Node64;
     D3 o, inv;
     double lo_t, hi_t;     // [t_min, current nearest t]
-    __device__ __forceinline__ void init(D3 o_, D3 d, double t_min, double t_max) {
+    __device__ __forceinline__ void init(const DScene&, D3 o_, D3 d, double t_min, double t_max) {
         o = o_; inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); lo_t = t_min; hi_t = t_max;
     }
     __device__ __forceinline__ void nearest(double best) { hi_t = best; }
@@ -105,27 +107,36 @@ struct Box64 {
 
 // Box32: conservative f32 test against boxes rounded OUTWARD to f32 (bvh_build.cpp: narrow_nodes).
 // It only culls; every accepted primitive is still intersected in f64, so (prim, t) stay bit-exact.
-// Error budget per slab plane b, with u = 2^-24, of = fl32(o), idf = fl32(1/d):
-//     T = fl32(fl32(b - of) * idf)   and the exact   t = (b - o)/d   satisfy
-//     |t - T| <= 3.1u |T| + 1.01u |of * idf|      (three roundings + the rounding of the origin)
-// so near = T - (|T| 2^-22 + c) and far = T + (|T| 2^-22 + c) with c = |of*idf| 2^-23 bracket t.
-// T -> T -/+ margin(T) is monotone, so the margins can be applied after min/max.  0*inf NaNs and
-// inf - inf NaNs drop out of fminf/fmaxf (IEEE minNum/maxNum), which only ever widens the interval;
-// the final comparisons are written negated so that a NaN accepts.
+// The kernels are bound by VALU issue in this test, so it is written as one fma per slab plane:
+//     Y = fma(b, idf, KN)            idf = fl32(1/d),  K = fl32(o * idf),  c = |K| 2^-21,  KN = fl32(-K - c)
+// (KF = fl32(-K + c) for the far planes).  Error budget, u = 2^-24, against the exact t = (b - o)/d:
+//     b*idf - K = (1 + e2)[t - A e3],   A = o/d,  |e2|, |e3| <= u          (rounding of idf and of K)
+//     Y = (b*idf - K - c + r)(1 + e4),  |r| <= u(|K| + c), |e4| <= u       (rounding of KN and of the fma)
+//     =>  t - Y >= -2.1u |Y| + (c - 3.1u |K|)  >=  -2.1u |Y|               (and symmetrically for KF)
+// so  Y - |Y| 2^-22  <= t for near planes and  Y + |Y| 2^-22 >= t  for far planes; y -> y -/+ |y| 2^-22 is
+// monotone and the same for the three axes, so it is applied once after max3 / min3.  0*inf and inf-inf
+// NaNs (rays parallel to a slab) drop out of fminf/fmaxf (IEEE minNum/maxNum), which only ever widens
+// the interval; the final comparisons are written negated so that a NaN accepts.
 struct Box32 {
     using Node = Node32;
-    float ox, oy, oz, ix, iy, iz, cx, cy, cz;
+    float ix, iy, iz, nx, ny, nz, fx, fy, fz;      // idf, KN, KF per axis
     float lo_t, hi_t;      // f32 bracket of [t_min, current nearest t]: lo_t <= t_min, hi_t >= nearest
     static __device__ __forceinline__ float f32_below(double x) { float f = (float)x; return f - fabsf(f) * 0x1.0p-22f; }
     static __device__ __forceinline__ float f32_above(double x) { float f = (float)x; return f + fabsf(f) * 0x1.0p-22f; }
     __device__ __forceinline__ void nearest(double best) { hi_t = f32_above(best); }
-    __device__ __forceinline__ void init(D3 o, D3 d, double t_min, double t_max) {
+    // o, inv in the space the boxes are given in (world for Box32, grid cells for Box16)
+    __device__ __forceinline__ void set_axis(double o, double inv, float& idf, float& kn, float& kf) {
+        idf = (float)inv;
+        const float K = (float)(o * (double)idf);
+        const float c = fmaf(fabsf(K), 0x1.0p-21f, 1e-30f);
+        kn = -K - c;
+        kf = -K + c;
+    }
+    __device__ __forceinline__ void init(const DScene&, D3 o, D3 d, double t_min, double t_max) {
         lo_t = f32_below(t_min); hi_t = f32_above(t_max);
-        ox = (float)o.x; oy = (float)o.y; oz = (float)o.z;
-        ix = (float)(1.0 / d.x); iy = (float)(1.0 / d.y); iz = (float)(1.0 / d.z);
-        cx = fmaf(fabsf(ox * ix), 0x1.0p-23f, 1e-30f);
-        cy = fmaf(fabsf(oy * iy), 0x1.0p-23f, 1e-30f);
-        cz = fmaf(fabsf(oz * iz), 0x1.0p-23f, 1e-30f);
+        set_axis(o.x, 1.0 / d.x, ix, nx, fx);
+        set_axis(o.y, 1.0 / d.y, iy, ny, fy);
+        set_axis(o.z, 1.0 / d.z, iz, nz, fz);
     }
     using Scalar = float;
     __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, float* lo_l, float* hi_l, float* lo_r, float* hi_r,
@@ -136,37 +147,39 @@ struct Box32 {
     }
     __device__ __forceinline__ bool test(const float* lo, const float* hi, float& t_near) const {
         const float r = 0x1.0p-22f;
-        float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-        float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-        float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-        float nx = fminf(ax, bx), fx = fmaxf(ax, bx);
-        float ny = fminf(ay, by), fy = fmaxf(ay, by);
-        float nz = fminf(az, bz), fz = fmaxf(az, bz);
-        nx -= fmaf(fabsf(nx), r, cx); fx += fmaf(fabsf(fx), r, cx);
-        ny -= fmaf(fabsf(ny), r, cy); fy += fmaf(fabsf(fy), r, cy);
-        nz -= fmaf(fabsf(nz), r, cz); fz += fmaf(fabsf(fz), r, cz);
-        float tn = fmaxf(fmaxf(nx, ny), nz);
-        float tf = fminf(fminf(fx, fy), fz);
+        const float ax = fminf(fmaf(lo[0], ix, nx), fmaf(hi[0], ix, nx)), bx = fmaxf(fmaf(lo[0], ix, fx), fmaf(hi[0], ix, fx));
+        const float ay = fminf(fmaf(lo[1], iy, ny), fmaf(hi[1], iy, ny)), by = fmaxf(fmaf(lo[1], iy, fy), fmaf(hi[1], iy, fy));
+        const float az = fminf(fmaf(lo[2], iz, nz), fmaf(hi[2], iz, nz)), bz = fmaxf(fmaf(lo[2], iz, fz), fmaf(hi[2], iz, fz));
+        float tn = fmaxf(fmaxf(ax, ay), az);
+        float tf = fminf(fminf(bx, by), bz);
+        tn = fmaf(-fabsf(tn), r, tn);
+        tf = fmaf(fabsf(tf), r, tf);
         t_near = tn;
         return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
     }
 };
 
-// Box16: the Box32 test on nodes quantised to the global 16-bit grid (Node16): half the bytes per
-// lane per step.  The decoded bound fmaf(q, cell, origin) is an f32 number that the builder checked
-// to enclose the f32 bound, so Box32's error budget applies unchanged.
+// Box16: the same test in GRID space for nodes quantised to the global 16-bit grid (Node16, Node4): the
+// ray is moved into cell units once (o' = (o - origin)/cell, 1/d' = cell/d, in f64 before the roundings the
+// budget above accounts for), and a box plane is the integer q itself — exact in f32, no decode arithmetic
+// per node.  The builder checks in exact arithmetic that origin + q*cell encloses every box.
 struct Box16 : Box32 {
     using Node = Node16;
+    __device__ __forceinline__ void init(const DScene& S, D3 o, D3 d, double t_min, double t_max) {
+        lo_t = f32_below(t_min); hi_t = f32_above(t_max);
+        const double cx = (double)S.grid.cell[0], cy = (double)S.grid.cell[1], cz = (double)S.grid.cell[2];
+        set_axis((o.x - (double)S.grid.origin[0]) / cx, cx / d.x, ix, nx, fx);
+        set_axis((o.y - (double)S.grid.origin[1]) / cy, cy / d.y, iy, ny, fy);
+        set_axis((o.z - (double)S.grid.origin[2]) / cz, cz / d.z, iz, nz, fz);
+    }
     __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, float* lo_l, float* hi_l, float* lo_r, float* hi_r,
                                           uint32_t& cl, uint32_t& cr) const {
         const uint4* p = reinterpret_cast<const uint4*>(&S.nodes16[cur]);
         const uint4 a = p[0], b = p[1];
-        const float ox_ = S.grid.origin[0], oy_ = S.grid.origin[1], oz_ = S.grid.origin[2];
-        const float sx = S.grid.cell[0], sy = S.grid.cell[1], sz = S.grid.cell[2];
-        lo_l[0] = fmaf((float)(a.x & 0xFFFFu), sx, ox_); lo_l[1] = fmaf((float)(a.x >> 16), sy, oy_); lo_l[2] = fmaf((float)(a.y & 0xFFFFu), sz, oz_);
-        hi_l[0] = fmaf((float)(a.y >> 16), sx, ox_);     hi_l[1] = fmaf((float)(a.z & 0xFFFFu), sy, oy_); hi_l[2] = fmaf((float)(a.z >> 16), sz, oz_);
-        lo_r[0] = fmaf((float)(a.w & 0xFFFFu), sx, ox_); lo_r[1] = fmaf((float)(a.w >> 16), sy, oy_);     lo_r[2] = fmaf((float)(b.x & 0xFFFFu), sz, oz_);
-        hi_r[0] = fmaf((float)(b.x >> 16), sx, ox_);     hi_r[1] = fmaf((float)(b.y & 0xFFFFu), sy, oy_); hi_r[2] = fmaf((float)(b.y >> 16), sz, oz_);
+        lo_l[0] = (float)(a.x & 0xFFFFu); lo_l[1] = (float)(a.x >> 16); lo_l[2] = (float)(a.y & 0xFFFFu);
+        hi_l[0] = (float)(a.y >> 16);     hi_l[1] = (float)(a.z & 0xFFFFu); hi_l[2] = (float)(a.z >> 16);
+        lo_r[0] = (float)(a.w & 0xFFFFu); lo_r[1] = (float)(a.w >> 16);     lo_r[2] = (float)(b.x & 0xFFFFu);
+        hi_r[0] = (float)(b.x >> 16);     hi_r[1] = (float)(b.y & 0xFFFFu); hi_r[2] = (float)(b.y >> 16);
         cl = b.z; cr = b.w;
     }
 };
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
         d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
     }
     BoxT rb;
-    rb.init(o, d, t_min, t_max);
+    rb.init(S, o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t cur = active ? S.root : REF_EMPTY;
@@ -276,6 +289,152 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
     }
 }
 
+// K1w — per-lane traversal of the BVH4 (Node4, 16-bit grid); the kernel bounce rays use when the scene has
+// one.  A step fetches one 64-byte node, tests its four child boxes in grid space (Box16), sorts the hit
+// children by entry distance (5 compare-exchanges), descends into the nearest and pushes the others
+// far-to-near: half the node fetches and dependent steps of the BVH2 walk per ray.  The box tests only
+// cull and the primitive tests are the same exact f64 ones, so (prim, t) do not change.
+// Lane refill: wave p owns the 64-entry chunks p, p + P, p + 2P, ... (P = gridDim.x) of the queue.  When
+// RT_REFILL_T or more lanes are idle and chunks are left, the finished lanes store their hits and take the
+// next rays.  Launched with P = number of chunks it is the plain one-chunk-per-wave kernel; launched with
+// P = resident waves it is persistent.  Every wave exits: chunks are consumed monotonically and the loop
+// ends when none is left and no lane holds a ray.  STACK >= S.stack4 (checked by the launcher).
+#ifndef RT_REFILL_T
+#define RT_REFILL_T 24
+#endif
+#ifdef RT_TRACE4_WAVES
+#define RT_T4_ATTR __attribute__((amdgpu_waves_per_eu(RT_TRACE4_WAVES, RT_TRACE4_WAVES)))
+#else
+#define RT_T4_ATTR
+#endif
+template <bool STATS, int STACK>
+__global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace4(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
+                                                                         HitBuf hb, unsigned long long* counters) {
+    __shared__ uint32_t stack[STACK][TRACE_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunks = qm.n_waves, stride = gridDim.x;
+    uint32_t next_chunk = blockIdx.x, chunk = 0, chunk_pos = 64;      // wave-uniform
+    bool busy = false;                                                // this lane holds a ray
+    uint32_t slot = 0;
+    D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+    Box16 rb;
+    rb.init(S, o, d, t_min, t_max);
+    double best = t_max, bu = 0.0, bv = 0.0;
+    uint32_t prim = RT_MISS;
+    uint32_t cur = REF_EMPTY;
+    int sp = 0;
+    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
+
+    for (;;) {
+        const bool at_node = !(cur & REF_LEAF);                 // REF_EMPTY has the leaf bit set
+        const bool at_leaf = !at_node && cur != REF_EMPTY;
+        const unsigned long long m_live = __ballot(at_node || at_leaf);
+        bool more = chunk_pos < 64u || next_chunk < n_chunks;
+        if (!m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T)) {
+            if (busy && cur == REF_EMPTY) {                           // retire
+                hb.t[slot] = prim == RT_MISS ? 0.0 : best;
+                hb.prim[slot] = prim;
+                hb.bu[slot] = bu;
+                hb.bv[slot] = bv;
+                busy = false;
+            }
+            while (more) {                                            // refill
+                const unsigned long long m_idle = __ballot(!busy);
+                if (!m_idle) break;
+                if (chunk_pos >= 64u) {
+                    chunk = next_chunk; next_chunk += stride; chunk_pos = 0;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                const uint32_t take = min((uint32_t)__popcll(m_idle), 64u - chunk_pos);
+                uint32_t i = 0;
+                if (!busy && rank < take && queue_slot(qm, chunk, chunk_pos + rank, i)) {
+                    slot = i; busy = true;
+                    o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+                    d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+                    rb.init(S, o, d, t_min, t_max);
+                    best = t_max; bu = 0.0; bv = 0.0; prim = RT_MISS;
+                    cur = S.root; sp = 0;
+                }
+                chunk_pos += take;
+                more = chunk_pos < 64u || next_chunk < n_chunks;
+            }
+            if (!__ballot(busy)) break;
+            continue;
+        }
+        if (STATS) ++n_iters;
+        // One dependent memory round trip per iteration for every lane: a node lane fetches its 64-byte node,
+        // a leaf lane ONE primitive of its leaf (80-byte triangle / 64-byte sphere); a leaf of n primitives
+        // takes n iterations (the reference keeps count and first, so it is advanced in place).  All loads are
+        // issued before anything waits, whatever mix of node and leaf lanes the wave holds.
+        const uint32_t first = cur & REF_FIRST_MASK;
+        const bool tri_leaf = at_leaf && !(cur & REF_SPHERE);
+        const char* src = at_node ? reinterpret_cast<const char*>(&S.nodes4[cur])
+                                  : tri_leaf ? reinterpret_cast<const char*>(&S.tris[first]) : reinterpret_cast<const char*>(&S.sphs[first]);
+        const uint4* p = reinterpret_cast<const uint4*>(src);
+        uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a;
+        if (at_node || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
+        if (tri_leaf) e = p[4];
+        if (at_node) {
+            if (STATS) ++n_nodes;
+            const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            uint32_t ref[4] = {r.x, r.y, r.z, r.w};
+            float key[4];
+            int n_hit = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
+                const uint32_t w0 = w[3 * k], w1 = w[3 * k + 1], w2 = w[3 * k + 2];
+                const float lo[3] = {(float)(w0 & 0xFFFFu), (float)(w0 >> 16), (float)(w1 & 0xFFFFu)};
+                const float hi[3] = {(float)(w1 >> 16), (float)(w2 & 0xFFFFu), (float)(w2 >> 16)};
+                float tn = 0.f;
+                const bool h = ref[k] != REF_EMPTY && rb.test(lo, hi, tn);
+                key[k] = h ? (tn < 3.0e38f ? tn : 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
+                n_hit += h ? 1 : 0;
+            }
+#define RT_CE(x, y) { const bool sw = key[y] < key[x]; const float kx = sw ? key[y] : key[x], ky = sw ? key[x] : key[y]; \
+                      const uint32_t rx = sw ? ref[y] : ref[x], ry = sw ? ref[x] : ref[y]; key[x] = kx; key[y] = ky; ref[x] = rx; ref[y] = ry; }
+            RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+            if (n_hit > 3) stack[sp++][tid] = ref[3];
+            if (n_hit > 2) stack[sp++][tid] = ref[2];
+            if (n_hit > 1) stack[sp++][tid] = ref[1];
+            cur = n_hit ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
+        }
+        if (at_leaf) {
+            if (STATS) { ++n_prims; ++n_leaves; }
+            if (tri_leaf) {                                           // TriGeom: a, e1, e2 (9 doubles), prim
+                const D3 ta = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
+                const D3 e1 = mk(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
+                const D3 e2 = mk(mkd(r.x, r.y), mkd(r.z, r.w), mkd(e.x, e.y));
+                double t, u, v;
+                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) { best = t; prim = e.z; bu = u; bv = v; rb.nearest(best); }
+            } else {                                                  // SphGeom: c, r, rot2 (7 doubles), prim
+                const D3 sc = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
+                const double sr = mkd(b.z, b.w);
+                const D3 rot2 = mk(mkd(c.x, c.y), mkd(c.z, c.w), mkd(r.x, r.y));
+                double t;
+                if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
+            }
+            // next primitive of the same leaf, or pop
+            cur = (cur & 0x30000000u) ? cur - 0x10000000u + 1u : (sp ? stack[--sp][tid] : REF_EMPTY);
+        }
+    }
+    if (STATS) {
+        unsigned long long a = n_nodes, b = n_prims, c = n_leaves;
+        for (int off = 32; off; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+            c += __shfl_xor(c, off);
+        }
+        if ((tid & 63u) == 0) {
+            atomicAdd(&counters[0], a);
+            atomicAdd(&counters[1], b);
+            atomicAdd(&counters[4], (unsigned long long)n_iters);
+            atomicAdd(&counters[5], c);
+        }
+    }
+}
+
 // K1r — the same traversal in PERSISTENT waves with lane refill.  Bounce rays end after very different
 // numbers of steps (sky escapes after a dozen nodes, grazing rays after a hundred), so in k_trace a wave
 // runs at the pace of its longest ray with about a third of its lanes busy.  Here the launch is one wave
@@ -298,7 +457,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace_refill(DS
     uint32_t slot = 0;
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     BoxT rb;
-    rb.init(o, d, t_min, t_max);
+    rb.init(S, o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t cur = REF_EMPTY;
@@ -331,7 +490,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace_refill(DS
                     slot = i; busy = true;
                     o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
                     d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
-                    rb.init(o, d, t_min, t_max);
+                    rb.init(S, o, d, t_min, t_max);
                     best = t_max; bu = 0.0; bv = 0.0; prim = RT_MISS;
                     cur = S.root; sp = 0;
                 }
@@ -416,7 +575,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // p must be wave-uniform: loads through the constant address space become s_load_dwordx16/x4
 __device__ __forceinline__ u32x16 uload16(const void* p) { return *(const RT_AS4 u32x16*)(uintptr_t)p; }
 __device__ __forceinline__ u32x4 uload4(const void* p) { return *(const RT_AS4 u32x4*)(uintptr_t)p; }
-__device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
 struct PacketEntry { uint32_t ref, mask_lo, mask_hi; };
 
@@ -443,7 +601,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
         }
     }
     Box32 rb;
-    rb.init(o, d, t_min, t_max);
+    rb.init(S, o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0;
@@ -736,6 +894,8 @@ static bool refill_enabled() {
     const char* n = getenv("RT_HIP_NO_REFILL");
     return e && atoi(e) == 1 && !(n && atoi(n) == 1);
 }
+// the BVH4 kernel refills by default (RT_HIP_NO_REFILL=1 launches it one chunk per wave)
+static bool refill4_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); return !(n && atoi(n) == 1); }
 static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
 template <class BoxT, int STACK>
 static void launch_trace_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
@@ -792,9 +952,32 @@ void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, con
     }
 }
 
+template <int STACK>
+static void launch_trace4_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
+                            unsigned long long* d_counters, hipStream_t s) {
+    // persistent (one wave per hardware slot, lanes refilled) once the queue holds several chunks per slot
+    static const unsigned slots_plain = resident_waves(k_trace4<false, STACK>);
+    static const unsigned slots_stats = resident_waves(k_trace4<true, STACK>);
+    const unsigned slots = refill_slots(stats ? slots_stats : slots_plain);
+    const bool persist = refill4_enabled() && qm.n_waves >= 2u * slots;
+    const dim3 grid(persist ? slots : qm.n_waves), block(TRACE_BLOCK);
+    if (stats)
+        hipLaunchKernelGGL((k_trace4<true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+    else
+        hipLaunchKernelGGL((k_trace4<false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+}
+
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
     if (!qm.n_waves) return;
+    if (S.nodes4 && S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
+        if (S.stack4 <= 16) launch_trace4_s<16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+        else if (S.stack4 <= 24) launch_trace4_s<24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+        else if (S.stack4 <= 32) launch_trace4_s<32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+        else if (S.stack4 <= 48) launch_trace4_s<48>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+        else launch_trace4_s<BVH4_MAX_STACK>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+        return;
+    }
     if (S.nodes16)
         launch_trace_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else if (S.nodes32)

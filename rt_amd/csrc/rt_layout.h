@@ -53,6 +53,18 @@ struct QuantGrid {
     float cell[3];
 };
 
+// BVH4 node on the same 16-bit grid: the boxes and references of up to four children in half a
+// 128-byte line.  Built by collapsing the BVH2 (bvh_build.cpp: widen_nodes).  Incoherent rays pay per
+// node FETCH (one L2 line request per lane, tools/micro/gather_bench.hip) and per dependent step, not
+// per byte, so halving the visits per ray is worth more than the bytes.  Unused slots come last and
+// hold REF_EMPTY.
+struct alignas(64) Node4 {
+    uint16_t box[4][6];      // child k: lo x, y, z, hi x, y, z
+    uint32_t child[4];
+};
+static_assert(sizeof(Node4) == 64, "Node4 layout");
+constexpr int BVH4_MAX_STACK = 64;   // widest per-lane stack a kernel instance provides
+
 // Triangle geometry in leaf order: a, e1 = b - a, e2 = c - a (src/hittable.rs:412-413), f64.
 struct alignas(16) TriGeom {
     double a[3], e1[3], e2[3];
@@ -102,6 +114,7 @@ struct DScene {
     const Node64* nodes64;
     const Node32* nodes32;
     const Node16* nodes16;       // optional (null when quantisation would inflate the leaves too much)
+    const Node4* nodes4;         // optional: BVH4 over the same leaves, same grid (per-lane traversal prefers it)
     const TriGeom* tris;
     const SphGeom* sphs;
     const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres
@@ -112,8 +125,9 @@ struct DScene {
     uint32_t n_spheres, n_prims;
     uint32_t root;               // REF_EMPTY for an empty scene, else 0
     uint32_t bvh_depth;          // deepest child reference = traversal stack entries needed
-    QuantGrid grid;              // of nodes16
-    uint32_t _pad2[2];
+    QuantGrid grid;              // of nodes16 and nodes4
+    uint32_t stack4;             // traversal stack entries nodes4 needs in the worst case
+    uint32_t _pad2[3];
     rt_sky sky;
 };
 

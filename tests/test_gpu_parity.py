@@ -252,27 +252,33 @@ def test_exact_ties_keep_t_bit_exact(cover, oracle):
 
 def test_node_formats_agree(monkeypatch, oracle):
     """RT_HIP_NODE_BOXES selects exact f64 boxes, conservative f32 boxes, or f32 boxes quantised to a
-    16-bit grid (default for the per-lane traversal when the grid is fine enough).  Boxes only cull:
-    all formats must give the same hits and the same image, bit for bit."""
+    16-bit grid, as BVH2 (q16) or collapsed to a BVH4 (w4: default for the per-lane traversal when the
+    grid is fine enough).  Boxes only cull: all formats must give the same hits and the same image, bit for bit."""
     desc = scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40)
     worlds = {}
-    for fmt in ("q16", "f32", "f64"):
+    for fmt in ("w4", "q16", "f32", "f64"):
         monkeypatch.setenv("RT_HIP_NODE_BOXES", fmt)
         worlds[fmt] = World.build(desc)
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
-    assert [worlds[f].info()["node_bytes"] for f in ("q16", "f32", "f64")] == [32, 64, 128]
+    worlds["default"] = World.build(desc)
+    assert [worlds[f].info()["node_bytes"] for f in ("w4", "q16", "f32", "f64")] == [64, 32, 64, 128]
+    assert [worlds[f].info()["bvh_width"] for f in ("default", "w4", "q16", "f32", "f64")] == [4, 4, 2, 2, 2]
     rays = np.concatenate([random_rays(40_000, 17), degenerate_rays(desc, 6)])
     hits = {f: w.hit(rays) for f, w in worlds.items()}
     assert_hits_equal(hits["f32"], hits["f64"])
     assert_hits_equal(hits["q16"], hits["f64"])
+    assert_hits_equal(hits["w4"], hits["f64"])
+    assert_hits_equal(hits["default"], hits["f64"])
     assert_hits_equal(hits["q16"], oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
     # on ordinary rays the wider margins / coarser boxes accept only a few extra nodes
     nv = {f: int(w.hit(rays[:40_000], with_stats=True)[1]["nodes_visited"]) for f, w in worlds.items()}
     assert nv["f64"] <= nv["f32"] <= nv["f64"] * 1.01 and nv["f32"] <= nv["q16"] <= nv["f32"] * 1.10
+    assert nv["w4"] < 0.7 * nv["q16"]                      # a BVH4 visit replaces about two BVH2 visits
     cam = Camera.new((9.0, -7.0, 4.0), (0.0, 0.0, 0.8), (0.0, 0.0, 1.0), 10.0, 0.3, 96, 64, 4, 12, 35.0)
     img = cam.render_image(worlds["f64"], spp=3, seed=2)
     assert np.array_equal(cam.render_image(worlds["f32"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["q16"], spp=3, seed=2), img)
+    assert np.array_equal(cam.render_image(worlds["w4"], spp=3, seed=2), img)
 
 
 def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypatch, cover, oracle):
@@ -285,7 +291,13 @@ def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypa
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
     assert forced.info()["node_bytes"] == 32
     rays = np.concatenate([random_rays(30_000, 23), degenerate_rays(desc, 8)])
-    assert_hits_equal(forced.hit(rays), orc.hit(rays, mode=oracle.BRUTE))
+    ref = orc.hit(rays, mode=oracle.BRUTE)
+    assert_hits_equal(forced.hit(rays), ref)
+    monkeypatch.setenv("RT_HIP_NODE_BOXES", "w4")
+    forced4 = World.build(desc)
+    monkeypatch.delenv("RT_HIP_NODE_BOXES")
+    assert forced4.info()["bvh_width"] == 4
+    assert_hits_equal(forced4.hit(rays), ref)
 
 
 def test_converged_image_relmse_at_4096_spp(cover, oracle):

@@ -5,7 +5,7 @@ set -u
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/ab_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp RT_HIP_PIPES=1
 cd /tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/log.txt 2>&1 || exit 1

@@ -47,8 +47,9 @@ def run(args):
                 continue
             j = json.loads(line[-1])
             rf = j["roofline"]
-            print(f"{n:24s} r{rnd} value={j['value']:8.1f} ms/step={j['ms_per_step']:8.2f} trace={rf['trace_fraction_of_step'] * j['ms_per_step']:7.2f}ms "
-                  f"shade={rf['shade_fraction_of_step'] * j['ms_per_step']:7.2f}ms bounce_rays/s={rf['trace_rays_per_s_bounces_only'] / 1e9:.3f}G", flush=True)
+            print(f"{n:24s} r{rnd} value={j['value']:8.1f} ms/step={j['ms_per_step']:8.2f} trace={j['trace_fraction_of_step'] * j['ms_per_step']:7.2f}ms "
+                  f"shade={j['shade_fraction_of_step'] * j['ms_per_step']:7.2f}ms bounce_rays/s={rf['rays_per_s'] / 1e9:.3f}G "
+                  f"packet_rays/s={j['roofline_packet']['rays_per_s'] / 1e9:.3f}G", flush=True)
 
 
 if __name__ == "__main__":
