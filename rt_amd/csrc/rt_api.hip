@@ -219,7 +219,11 @@ int check_camera(const rt_camera* cam) {
     return RT_OK;
 }
 
-constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 25;
+// 2^27 paths = 64 samples per pixel and pass at 1080p: 204 B of path state each, two workspaces (two passes in
+// flight) = 55 GB of the 288 GB.  Measured on the 1 M-triangle frame: 2^25 -> 4437, 2^26 -> 4658, 2^27 -> 4783 Msamples/s
+// (fewer, larger launches; tails and host round trips amortised over 4x the work).
+constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 27;
+constexpr size_t PRIMARY_MAX_PIXELS = size_t(1) << 25;
 
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
 int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
@@ -233,7 +237,9 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         return fail(RT_ERR_LIMIT, "sample index %llu exceeds the Halton table limit %u (src/camera.rs:208-210)",
                     (unsigned long long)last, RT_MAX_SAMPLE_INDEX);
     const size_t npix = (size_t)cam->width * cam->height;
-    const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : DEFAULT_PATHS_IN_FLIGHT;
+    const char* pfe = getenv("RT_HIP_PATHS_IN_FLIGHT");          // experiments: log2 of the default cap
+    const size_t dflt = pfe && atoi(pfe) >= 10 && atoi(pfe) <= 30 ? size_t(1) << atoi(pfe) : DEFAULT_PATHS_IN_FLIGHT;
+    const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
     const uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
     const uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
@@ -260,6 +266,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     pp0.pass_base = 0;
     pp0.jitter = 1;
     pp0.tiled = 1;
+    pp0.group = 1;
+    // samples of a pixel that share a wave of camera rays: as many as the pass and the frame allow
+    // (RT_HIP_GROUP=1|4|16|64 caps it; 1 = one sample of an 8x8 tile per wave)
+    const char* ge = getenv("RT_HIP_GROUP");
+    const uint32_t group_cap = ge && atoi(ge) > 0 ? (uint32_t)atoi(ge) : 16u;
 
     rt_stats st;
     memset(&st, 0, sizeof(st));
@@ -316,6 +327,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         P.n = (uint32_t)(npix * P.nl);
         P.pp = pp0;
         P.pp.pass_base = base;
+        for (uint32_t g = 64; g > 1; g >>= 2)
+            if (g <= group_cap && P.nl % g == 0 && npix % (64u / g) == 0) { P.pp.group = g; break; }
         P.depth = 0;
         P.cur = 0;
         P.qm = queue_map_single(P.n);
@@ -739,7 +752,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     if (rc) return rc;
     if (sample_index >= RT_MAX_SAMPLE_INDEX) return fail(RT_ERR_LIMIT, "sample index beyond the Halton table");
     const size_t npix = (size_t)cam->width * cam->height;
-    if (npix > DEFAULT_PATHS_IN_FLIGHT) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^25 pixels");
+    if (npix > PRIMARY_MAX_PIXELS) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^25 pixels");
     std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
     std::lock_guard<std::mutex> sl(sc->mu);
     if ((rc = select_device(sc->device))) return rc;
@@ -759,6 +772,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.pass_base = 0;
     pp.jitter = jitter ? 1 : 0;
     pp.tiled = 0;
+    pp.group = 1;
     hipStream_t stream = nullptr;
     const QueueMap qm = queue_map_single((uint32_t)npix);
     launch_raygen(pp, qm, w.q[0], stream);

@@ -71,16 +71,19 @@ __device__ __forceinline__ double halton3(uint32_t index) {
 }
 
 // ---- path slot -> pixel --------------------------------------------------------------------
-// Slots enumerate the full 8x8 tiles first (tile-major, row-major inside a tile), then the right
-// strip, then the bottom strip, so that a wave's 64 primary rays cover an 8x8 pixel block.
+// Slots enumerate the full 8x8 tiles first (tile-major, Z-order inside a tile: any aligned run of 4, 16
+// or 64 slots is a 2x2, 4x4 or 8x8 pixel block), then the right strip, then the bottom strip.
+__device__ __forceinline__ uint32_t compact3(uint32_t v) {      // bits 0, 2, 4 -> 0, 1, 2
+    return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u);
+}
 __device__ __forceinline__ uint32_t slot_to_pixel(uint32_t slot, uint32_t W, uint32_t H, uint32_t tiled) {
     if (!tiled) return slot;
     const uint32_t W8 = W & ~7u, H8 = H & ~7u, nfull = W8 * H8;
     uint32_t x, y;
     if (slot < nfull) {
         const uint32_t tile = slot >> 6, in = slot & 63u, tpr = W8 >> 3;
-        x = (tile % tpr) * 8u + (in & 7u);
-        y = (tile / tpr) * 8u + (in >> 3);
+        x = (tile % tpr) * 8u + compact3(in);
+        y = (tile / tpr) * 8u + compact3(in >> 1);
     } else {
         uint32_t r = slot - nfull;
         const uint32_t wr = W - W8;
@@ -94,6 +97,30 @@ __device__ __forceinline__ uint32_t slot_to_pixel(uint32_t slot, uint32_t W, uin
         }
     }
     return y * W + x;
+}
+
+// ---- path id <-> (pixel slot, local sample) ----------------------------------------------------
+// group G = samples of one pixel that share a wave of camera rays (1, 4, 16 or 64): a wave of 64 consecutive
+// path ids holds G samples of each of 64/G neighbouring pixels.  The rays of one pixel differ only by the
+// sub-pixel jitter, so the wave of the packet traversal walks (almost) one ray's nodes instead of the union
+// over an 8x8 tile.  G == 1 is the plain sample-major order.  G > 1 needs n_pixels % (64/G) == 0 and a
+// sample count per pass that is a multiple of G (the host checks).
+__device__ __forceinline__ void pid_to_slot_sample(uint32_t pid, uint32_t n_pixels, uint32_t G, uint32_t& slot, uint32_t& local) {
+    if (G <= 1u) {
+        local = pid / n_pixels;
+        slot = pid - local * n_pixels;
+        return;
+    }
+    const uint32_t P = 64u / G, per_group = n_pixels * G;
+    const uint32_t sg = pid / per_group, r = pid - sg * per_group;
+    const uint32_t lane = r & 63u;
+    slot = (r >> 6) * P + (lane & (P - 1u));
+    local = sg * G + lane / P;
+}
+__device__ __forceinline__ size_t slot_sample_to_pid(uint32_t slot, uint32_t local, uint32_t n_pixels, uint32_t G) {
+    if (G <= 1u) return (size_t)local * n_pixels + slot;
+    const uint32_t P = 64u / G;
+    return (size_t)(local / G) * ((size_t)n_pixels * G) + (size_t)(slot / P) * 64u + (local % G) * P + (slot % P);
 }
 
 // ---- sharded queue addressing ----------------------------------------------------------------

@@ -16,6 +16,7 @@ struct PassParams {
     uint32_t pass_base;                      // first local sample of this pass
     uint32_t jitter;                         // 0: debug_ray (pixel centres, pinhole)
     uint32_t tiled;                          // 1: path slots enumerate pixels in 8x8 tiles (coherent waves)
+    uint32_t group;                          // samples of a pixel per wave of camera rays (rt_device.h: pid_to_slot_sample)
 };
 
 // K0: primary rays for path ids [0, n_paths) -> queue

@@ -24,8 +24,9 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // Camera::get_ray for path id `pid` of the pass (src/camera.rs:231-254)
 __device__ __forceinline__ void camera_ray(const PassParams& pp, uint32_t pid, D3& origin, D3& dir) {
-    uint32_t local = pid / pp.n_pixels;
-    uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
+    uint32_t local, pslot;
+    pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
+    uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
     uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
     uint32_t x = pixel % pp.cam.width, y = pixel / pp.cam.width;
     double ox = pp.jitter ? halton2(sample) : 0.0;      // rng_map[i] (src/camera.rs:239)
@@ -578,6 +579,7 @@ __device__ __forceinline__ u32x4 uload4(const void* p) { return *(const RT_AS4 u
 
 struct PacketEntry { uint32_t ref, mask_lo, mask_hi; };
 
+
 // GEN: the wave generates its own camera rays (K0 fused in: saves the queue round trip of k_raygen)
 // and stores them for k_shade.
 template <bool STATS, bool GEN>
@@ -744,8 +746,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
             }
             const ShadeMat* m = &S.mats[h.material];
             const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
-            const uint32_t local = pid / pp.n_pixels;
-            const uint32_t pixel = slot_to_pixel(pid - local * pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled);
+            uint32_t local, pslot;
+            pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
+            const uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
             RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
             D3 att, dir;
             if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
@@ -826,13 +829,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
 // K5 — per-pixel sum in sample order, and the final mean
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radiance, uint32_t n_pixels, uint32_t W, uint32_t H,
-                                                      uint32_t tiled, uint32_t n_local, double* rgb_sum) {
+                                                      uint32_t tiled, uint32_t group, uint32_t n_local, double* rgb_sum) {
     uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= n_pixels) return;
     const uint32_t pixel = slot_to_pixel(slot, W, H, tiled);
     double r = rgb_sum[3 * (size_t)pixel], g = rgb_sum[3 * (size_t)pixel + 1], b = rgb_sum[3 * (size_t)pixel + 2];
     for (uint32_t s = 0; s < n_local; ++s) {
-        const double* L = &path_radiance[3 * ((size_t)s * n_pixels + slot)];
+        const double* L = &path_radiance[3 * slot_sample_to_pid(slot, s, n_pixels, group)];
         r += L[0]; g += L[1]; b += L[2];
     }
     rgb_sum[3 * (size_t)pixel] = r; rgb_sum[3 * (size_t)pixel + 1] = g; rgb_sum[3 * (size_t)pixel + 2] = b;
@@ -939,17 +942,12 @@ void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, con
     const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
     PassParams pp;
     if (gen) pp = *gen; else memset(&pp, 0, sizeof(pp));
-    if (gen) {
-        if (stats)
-            hipLaunchKernelGGL((k_trace_packet<true, true>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
-        else
-            hipLaunchKernelGGL((k_trace_packet<false, true>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
-    } else {
-        if (stats)
-            hipLaunchKernelGGL((k_trace_packet<true, false>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
-        else
-            hipLaunchKernelGGL((k_trace_packet<false, false>), grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters);
-    }
+    // (a BVH4 variant of this kernel — four boxes per s_load, stack in VGPR lanes — was measured 8 % slower:
+    // the wave tests all four boxes of every node on all lanes, and the node steps were not the bound)
+#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters)
+    if (gen) { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true>)); }
+    else     { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, false>)); }
+#undef RT_LAUNCH_PACKET
 }
 
 template <int STACK>
@@ -1048,7 +1046,7 @@ void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint
                        hipStream_t s) {
     if (!pp.n_pixels || !n_local) return;
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(pp.n_pixels)), dim3(BLOCK), 0, s, d_path_radiance, pp.n_pixels,
-                       pp.cam.width, pp.cam.height, pp.tiled, n_local, d_rgb_sum);
+                       pp.cam.width, pp.cam.height, pp.tiled, pp.group, n_local, d_rgb_sum);
 }
 void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
     if (!n) return;

@@ -336,3 +336,22 @@ def test_persistent_refill_kernel_is_bit_exact(monkeypatch, cover, mixed, oracle
     assert np.array_equal(img, img0)
     for k in ("ray_segments", "nodes_visited", "prims_tested"):
         assert int(st[k]) == int(st0[k])
+
+
+def test_sample_grouping_of_camera_waves_does_not_change_the_image(monkeypatch, cover):
+    """RT_HIP_GROUP: how many samples of a pixel share a wave of camera rays (path-id layout only).  RNG keys
+    and the per-pixel sum order do not depend on it, so every grouping gives the same image bit for bit."""
+    desc, world, _ = cover
+    cam = scenes.cover_camera(96, 64, spp=64, max_depth=12, defocus=True)
+    imgs = {}
+    for g in (1, 4, 16, 64):
+        monkeypatch.setenv("RT_HIP_GROUP", str(g))
+        imgs[g], st = cam.render_image(world, spp=64, seed=9, with_stats=True)
+        assert int(st["samples"]) == 96 * 64 * 64
+    for g in (4, 16, 64):
+        assert np.array_equal(imgs[g], imgs[1]), g
+    monkeypatch.setenv("RT_HIP_GROUP", "16")                 # ragged: 50 samples -> passes fall back to smaller groups
+    odd = scenes.cover_camera(70, 38, spp=50, max_depth=12, defocus=True)
+    a = odd.render_image(world, spp=50, seed=2)
+    monkeypatch.setenv("RT_HIP_GROUP", "1")
+    assert np.array_equal(a, odd.render_image(world, spp=50, seed=2))
