@@ -276,6 +276,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
     const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
+    const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");      // depth-0 shading inside the camera-ray kernel
 
     struct Pipe {
         Workspace* w = nullptr;
@@ -309,13 +310,18 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         P.ob = shard_bases_for(P.qm);
         HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, P.s));
         HIPCHK(hipEventRecord(w.ev[2], P.s));
-        if (P.depth == 0 && use_packet)   // camera rays of 8x8 tiles: coherent; generated in the kernel
-            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters + 2, P.s);
-        else
+        bool shaded = false;
+        if (P.depth == 0 && use_packet) {   // camera rays: coherent waves; generated, traced and (fused) shaded in one kernel
+            PacketFuse f = {w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance};
+            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters + 2, P.s,
+                                fuse_shade ? &f : nullptr);
+            shaded = fuse_shade;
+        } else {
             launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats,
                          w.stat_counters + (P.depth == 0 ? 2 : 0), P.s);
+        }
         HIPCHK(hipEventRecord(w.ev[3], P.s));
-        launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], P.qm, w.hb, w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance, P.s);
+        if (!shaded) launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], P.qm, w.hb, w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance, P.s);
         HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
         HIPCHK(hipEventRecord(w.ev[4], P.s));
         return RT_OK;

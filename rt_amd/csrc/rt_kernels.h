@@ -28,9 +28,17 @@ void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min,
                   bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
 // K1p: the same for coherent waves (camera rays in 8x8 tiles): wave-level packet traversal through the scalar cache
 // gen != NULL: the kernel generates the camera rays of that pass itself (K0 fused) and stores them in q
+// fuse != NULL (needs gen): the kernel also shades depth 0 and appends the survivors to fuse->q_out (the launch
+// of k_shade for depth 0 is then skipped; q and hb receive nothing but the barycentrics of triangle hits)
+struct PacketFuse {
+    RayQueue q_out;
+    ShardBases out_bases;
+    uint32_t* d_out_counts;
+    double* d_path_radiance;
+};
 bool packet_supported(const DScene& S);
 void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
-                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s);
+                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s, const PacketFuse* fuse = nullptr);
 // sharded-queue bookkeeping (host): a dense queue of n entries; the output bases of a shade launch
 // over `in`; the map of the queue that launch produced, from its NSHARD counters (32 u32 apart)
 QueueMap queue_map_single(uint32_t n);

@@ -580,11 +580,20 @@ __device__ __forceinline__ u32x4 uload4(const void* p) { return *(const RT_AS4 u
 struct PacketEntry { uint32_t ref, mask_lo, mask_hi; };
 
 
+__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
+                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
+                                           double* path_radiance, D3& no, D3& nd, D3& nthr);
+__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, const ShardBases& ob,
+                                             uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr);
+
 // GEN: the wave generates its own camera rays (K0 fused in: saves the queue round trip of k_raygen)
 // and stores them for k_shade.
-template <bool STATS, bool GEN>
+// FUSE (with GEN): the wave also shades its hits (depth 0) and appends the survivors to qo, so neither the
+// camera rays nor their hit records travel through HBM (k_shade at depth 0 is bound by exactly that traffic).
+template <bool STATS, bool GEN, bool FUSE>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueMap qm, double t_min,
-                                                               double t_max, HitBuf hb, unsigned long long* counters) {
+                                                               double t_max, HitBuf hb, unsigned long long* counters,
+                                                               RayQueue qo, ShardBases ob, uint32_t* out_counts, double* path_radiance) {
     __shared__ PacketEntry stack[BVH_MAX_DEPTH];
     const uint32_t lane = threadIdx.x;
     uint32_t i = 0;
@@ -594,9 +603,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
         if (GEN) {
             const uint32_t pid = blockIdx.x * TRACE_BLOCK + lane;
             camera_ray(pp, pid, o, d);
-            q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
-            q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
-            q.pid[i] = pid;
+            if (!FUSE) {
+                q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
+                q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
+                q.pid[i] = pid;
+            }
         } else {
             o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
             d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
@@ -678,7 +689,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
         cur = __builtin_amdgcn_readfirstlane(e.ref);
         mask = ((unsigned long long)__builtin_amdgcn_readfirstlane(e.mask_hi) << 32) | __builtin_amdgcn_readfirstlane(e.mask_lo);
     }
-    if (active) {
+    if (FUSE) {
+        bool alive = false;
+        D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
+        const uint32_t pid = blockIdx.x * TRACE_BLOCK + lane;
+        if (active) {
+            if (prim != RT_MISS) { hb.bu[i] = bu; hb.bv[i] = bv; }      // read back only by textured triangles
+            alive = shade_path(S, pp, 0u, pid, i, o, d, mk(1.0, 1.0, 1.0), prim, best, hb, path_radiance, no, nd, nthr);
+        }
+        queue_append(alive, blockIdx.x, lane, qo, ob, out_counts, pid, no, nd, nthr);
+    } else if (active) {
         hb.t[i] = prim == RT_MISS ? 0.0 : best;
         hb.prim[i] = prim;
         hb.bu[i] = bu;
@@ -700,6 +720,124 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
 // ---------------------------------------------------------------------------------------------
 // K2-K4 — shade + Russian roulette + compaction
 // ---------------------------------------------------------------------------------------------
+// One path vertex: sky on a miss, else the intersection record, Material::scatter and russian_roulette.
+// Returns whether the path goes on (then no, nd, nthr are the next ray and throughput); a path that ends
+// writes its radiance slot.  bu/bv are read lazily through hb (only textured triangles need them).
+__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
+                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
+                                           double* path_radiance, D3& no, D3& nd, D3& nthr) {
+    bool alive = false;
+    D3 L = mk(0.0, 0.0, 0.0);
+    if (prim == RT_MISS) {
+        // Camera::raycast miss branch (src/camera.rs:308-312)
+        D3 dir = normalize(d);
+        L = mul(thr, sky_color_toward(S.sky, dir));
+    } else {
+        SurfaceHit h;
+        h.bu = &hb.bu[i]; h.bv = &hb.bv[i];
+        h.is_sphere = prim < S.n_spheres;
+        h.ts = nullptr; h.ss = nullptr;
+        if (h.is_sphere) {                                      // Sphere::hit tail (src/hittable.rs:340-346)
+            const SphShade* ss = &S.sph_shade[prim];
+            h.ss = ss;
+            h.p = add(scale(d, t), o);
+            h.n = divs(sub(h.p, ld3(ss->c)), ss->r);
+            h.front = dot(d, h.n) < 0.0;
+            if (!h.front) h.n = neg(h.n);
+            h.material = ss->material;
+        } else {                                                // Triangle::hit tail (:463-464)
+            const TriShade* ts = &S.tri_shade[prim - S.n_spheres];
+            h.ts = ts;
+            h.p = add(o, scale(d, t));
+            h.n = ld3(ts->n);
+            h.front = dot(d, h.n) <= 0.0;
+            h.material = ts->material;
+        }
+        const ShadeMat* m = &S.mats[h.material];
+        const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
+        uint32_t local, pslot;
+        pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
+        const uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
+        RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
+        D3 att, dir;
+        if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
+            double ior = m->ior;
+            double ri = h.front ? 1.0 / ior : ior;
+            D3 din = normalize(d);
+            double c = fmin(-dot(din, h.n), 1.0);
+            double sn = sqrt(1.0 - c * c);
+            bool cannot = ri * sn > 1.0;
+            U4 b0 = rng_block(key, 0);
+            double noise = u64_to_unit(b0.x, b0.y);             // slot 0
+            if (cannot || reflectance(c, ri) > noise) {
+                dir = reflect(din, h.n);
+            } else {
+                dir = refract(din, h.n, ri);
+                if (has_fuzz) {
+                    U4 b1 = rng_block(key, 1);
+                    D3 ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
+                                         2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
+                    dir = add(dir, scale(ru, m->fuzz));
+                }
+            }
+            dir = normalize(dir);
+            att = mk(1.0, 1.0, 1.0);
+        } else {
+            D3 ru = mk(0, 0, 0);
+            if (kind == RT_MAT_LAMBERTIAN || has_fuzz) {        // Vec3::random_unit, slots 1,2,3 (src/vec3.rs:113-120)
+                U4 b0 = rng_block(key, 0), b1 = rng_block(key, 1);
+                ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
+                                  2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
+            }
+            if (kind == RT_MAT_LAMBERTIAN) {                    // src/material.rs:110-120
+                dir = add(h.n, ru);
+                if (near_zero(dir)) dir = h.n;
+            } else {                                            // Metal (:94-108)
+                dir = reflect(d, h.n);
+                if (has_fuzz) dir = add(dir, scale(ru, m->fuzz));
+            }
+            att = m->tex_kind == RT_TEX_SOLID ? ld3(m->rgb) : texture_value(S, m->texture, h);
+        }
+        dir = normalize(dir);                                   // Ray::new(point, dir)
+        if (depth < pp.cam.max_depth) {                         // src/camera.rs:300
+            double p = fmax(fmax(att.x, att.y), att.z);         // russian_roulette (:280-293)
+            U4 b2 = rng_block(key, 2);
+            if (u64_to_unit(b2.x, b2.y) < p) {                  // slot 4
+                alive = true;
+                nthr = mul(thr, divs(scale(att, 1.0), p));
+                no = h.p;
+                nd = dir;
+            }
+        }
+    }
+    if (!alive) {
+        path_radiance[3 * (size_t)pid + 0] = L.x;
+        path_radiance[3 * (size_t)pid + 1] = L.y;
+        path_radiance[3 * (size_t)pid + 2] = L.z;
+    }
+    return alive;
+}
+
+// K4: survivors of logical wave `wave` are appended to its output shard: wave64 ballot + prefix count, one
+// atomic per wave on that shard's counter (counters sit 128 B apart).  Called by all 64 lanes.
+__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, const ShardBases& ob,
+                                             uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr) {
+    const unsigned long long mask = __ballot(alive);
+    if (mask) {
+        const uint32_t shard = wave & (NSHARD - 1);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(out_counts + 32 * shard, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0) + ob.base[shard];
+        if (alive) {
+            const uint32_t j = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            qo.o[0][j] = no.x; qo.o[1][j] = no.y; qo.o[2][j] = no.z;
+            qo.d[0][j] = nd.x; qo.d[1][j] = nd.y; qo.d[2][j] = nd.z;
+            qo.thr[0][j] = nthr.x; qo.thr[1][j] = nthr.y; qo.thr[2][j] = nthr.z;
+            qo.pid[j] = pid;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueMap qm,
                                                  HitBuf hb, RayQueue qo, ShardBases ob, uint32_t* out_counts,
                                                  double* path_radiance) {
@@ -717,112 +855,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
         // depth 0: the throughput is (1,1,1) by construction (k_raygen writes it, nobody needs to read it)
         const D3 thr = depth == 0 ? mk(1.0, 1.0, 1.0) : mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
         const uint32_t prim = hb.prim[i];
-        D3 L = mk(0.0, 0.0, 0.0);
-        if (prim == RT_MISS) {
-            // Camera::raycast miss branch (src/camera.rs:308-312)
-            D3 dir = normalize(d);
-            L = mul(thr, sky_color_toward(S.sky, dir));
-        } else {
-            const double t = hb.t[i];
-            SurfaceHit h;
-            h.bu = &hb.bu[i]; h.bv = &hb.bv[i];
-            h.is_sphere = prim < S.n_spheres;
-            h.ts = nullptr; h.ss = nullptr;
-            if (h.is_sphere) {                                      // Sphere::hit tail (src/hittable.rs:340-346)
-                const SphShade* ss = &S.sph_shade[prim];
-                h.ss = ss;
-                h.p = add(scale(d, t), o);
-                h.n = divs(sub(h.p, ld3(ss->c)), ss->r);
-                h.front = dot(d, h.n) < 0.0;
-                if (!h.front) h.n = neg(h.n);
-                h.material = ss->material;
-            } else {                                                // Triangle::hit tail (:463-464)
-                const TriShade* ts = &S.tri_shade[prim - S.n_spheres];
-                h.ts = ts;
-                h.p = add(o, scale(d, t));
-                h.n = ld3(ts->n);
-                h.front = dot(d, h.n) <= 0.0;
-                h.material = ts->material;
-            }
-            const ShadeMat* m = &S.mats[h.material];
-            const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
-            uint32_t local, pslot;
-            pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
-            const uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
-            RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
-            D3 att, dir;
-            if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
-                double ior = m->ior;
-                double ri = h.front ? 1.0 / ior : ior;
-                D3 din = normalize(d);
-                double c = fmin(-dot(din, h.n), 1.0);
-                double s = sqrt(1.0 - c * c);
-                bool cannot = ri * s > 1.0;
-                U4 b0 = rng_block(key, 0);
-                double noise = u64_to_unit(b0.x, b0.y);             // slot 0
-                if (cannot || reflectance(c, ri) > noise) {
-                    dir = reflect(din, h.n);
-                } else {
-                    dir = refract(din, h.n, ri);
-                    if (has_fuzz) {
-                        U4 b1 = rng_block(key, 1);
-                        D3 ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
-                                             2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
-                        dir = add(dir, scale(ru, m->fuzz));
-                    }
-                }
-                dir = normalize(dir);
-                att = mk(1.0, 1.0, 1.0);
-            } else {
-                D3 ru = mk(0, 0, 0);
-                if (kind == RT_MAT_LAMBERTIAN || has_fuzz) {        // Vec3::random_unit, slots 1,2,3 (src/vec3.rs:113-120)
-                    U4 b0 = rng_block(key, 0), b1 = rng_block(key, 1);
-                    ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
-                                      2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
-                }
-                if (kind == RT_MAT_LAMBERTIAN) {                    // src/material.rs:110-120
-                    dir = add(h.n, ru);
-                    if (near_zero(dir)) dir = h.n;
-                } else {                                            // Metal (:94-108)
-                    dir = reflect(d, h.n);
-                    if (has_fuzz) dir = add(dir, scale(ru, m->fuzz));
-                }
-                att = m->tex_kind == RT_TEX_SOLID ? ld3(m->rgb) : texture_value(S, m->texture, h);
-            }
-            dir = normalize(dir);                                   // Ray::new(point, dir)
-            if (depth < pp.cam.max_depth) {                         // src/camera.rs:300
-                double p = fmax(fmax(att.x, att.y), att.z);         // russian_roulette (:280-293)
-                U4 b2 = rng_block(key, 2);
-                if (u64_to_unit(b2.x, b2.y) < p) {                  // slot 4
-                    alive = true;
-                    nthr = mul(thr, divs(scale(att, 1.0), p));
-                    no = h.p;
-                    nd = dir;
-                }
-            }
-        }
-        if (!alive) {
-            path_radiance[3 * (size_t)pid + 0] = L.x;
-            path_radiance[3 * (size_t)pid + 1] = L.y;
-            path_radiance[3 * (size_t)pid + 2] = L.z;
-        }
+        const double t = prim == RT_MISS ? 0.0 : hb.t[i];
+        alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, t, hb, path_radiance, no, nd, nthr);
     }
-    // K4: wave64 ballot + prefix count, one atomic per wave, on the counter of the wave's output
-    // shard (counters sit 128 B apart)
-    const unsigned long long mask = __ballot(alive);
-    if (mask) {
-        const uint32_t shard = wave & (NSHARD - 1);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(out_counts + 32 * shard, (uint32_t)__popcll(mask));
-        base = __shfl(base, 0) + ob.base[shard];
-        if (alive) {
-            const uint32_t j = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            qo.o[0][j] = no.x; qo.o[1][j] = no.y; qo.o[2][j] = no.z;
-            qo.d[0][j] = nd.x; qo.d[1][j] = nd.y; qo.d[2][j] = nd.z;
-            qo.thr[0][j] = nthr.x; qo.thr[1][j] = nthr.y; qo.thr[2][j] = nthr.z;
-            qo.pid[j] = pid;
-        }
-    }
+    queue_append(alive, wave, lane, qo, ob, out_counts, pid, no, nd, nthr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,16 +973,20 @@ static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, doub
 bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant
 
 void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
-                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s) {
+                         HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s, const PacketFuse* fuse) {
     if (!qm.n_waves) return;
     const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
     PassParams pp;
     if (gen) pp = *gen; else memset(&pp, 0, sizeof(pp));
+    PacketFuse f;
+    if (fuse && gen) f = *fuse; else memset(&f, 0, sizeof(f));
     // (a BVH4 variant of this kernel — four boxes per s_load, stack in VGPR lanes — was measured 8 % slower:
     // the wave tests all four boxes of every node on all lanes, and the node steps were not the bound)
-#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters)
-    if (gen) { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true>)); }
-    else     { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, false>)); }
+#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters, \
+                                               f.q_out, f.out_bases, f.d_out_counts, f.d_path_radiance)
+    if (fuse && gen) { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true, true>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true, true>)); }
+    else if (gen)    { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true, false>)); }
+    else             { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, false, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, false, false>)); }
 #undef RT_LAUNCH_PACKET
 }
 
