@@ -110,7 +110,7 @@ def pmc_traffic(workload):
     k = json.load(open(files[-1]))["kernels"]
     pick = lambda pre: next((v["traffic_bytes_per_launch"] for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
                              if n.startswith(pre)), None)
-    return pick("k_trace<"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1])
+    return (pick("k_trace4<") or pick("k_trace<")), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1])
 
 
 def main():
@@ -211,7 +211,11 @@ def main():
         bounce_launches = n_launch - sum(int(s["passes"]) for s in stats)
         achieved = bounce_seg * bytes_per_seg / bounce_s / 1e9 if bounce_s > 0 else 0.0
         pv_n, pv_p = s_pnodes / max(1, s_pseg), s_pprims / max(1, s_pseg)
-        p_bytes_per_seg = 28 + 72 + pv_n * 64 + pv_p * prim_bytes   # hit record out, generated ray out (fused raygen)
+        # the camera-ray kernel generates its rays and shades its own hits: per segment it writes the radiance slot of
+        # a path that ends (24 B) or the next ray of one that goes on (76 B: o, d, throughput, path id); the share
+        # that goes on is at most bounce segments / camera segments
+        a_on = min(1.0, (s_seg - s_pseg) / max(1, s_pseg))
+        p_bytes_per_seg = 24 * (1 - a_on) + 76 * a_on + pv_n * 64 + pv_p * prim_bytes
         p_achieved = prim_seg * p_bytes_per_seg / prim_s / 1e9 if prim_s > 0 else 0.0
         traffic, p_traffic, traffic_src = pmc_traffic(args.workload)
         img = rgb_mean.cpu().numpy()
@@ -224,7 +228,7 @@ def main():
                        "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_trace (per-lane traversal of bounce segments)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_trace4 (per-lane BVH4 traversal of bounce segments)" if info.get("bvh_width") == 4 else "k_trace (per-lane BVH2 traversal of bounce segments)",
                          "avg_launch_ms": bounce_s / max(1, bounce_launches) * 1e3, "launches": bounce_launches,
                          "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
                          "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
@@ -232,7 +236,7 @@ def main():
                          "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak; "
                                  "two passes run on two streams, so event-timed kernel durations include time shared with the other pass" % (info["device_bytes"] / 2 ** 20)},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic, "kernel": "k_trace_packet (camera rays, fused raygen)",
+                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic, "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading)",
                                 "avg_launch_ms": prim_s / max(1, n_launch - bounce_launches) * 1e3,
                                 "launches": n_launch - bounce_launches, "segments": prim_seg,
                                 "bytes_per_segment": p_bytes_per_seg, "nodes_per_segment": pv_n, "prims_per_segment": pv_p,
