@@ -320,8 +320,8 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     Box16 rb;
     rb.init(S, o, d, t_min, t_max);
-    double best = t_max, bu = 0.0, bv = 0.0;
-    uint32_t prim = RT_MISS;
+    double best = t_max;                                              // (barycentrics go to hb when a hit is accepted:
+    uint32_t prim = RT_MISS;                                          //  four registers fewer across the loop)
     uint32_t cur = REF_EMPTY;
     int sp = 0;
     uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
@@ -335,8 +335,6 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             if (busy && cur == REF_EMPTY) {                           // retire
                 hb.t[slot] = prim == RT_MISS ? 0.0 : best;
                 hb.prim[slot] = prim;
-                hb.bu[slot] = bu;
-                hb.bv[slot] = bv;
                 busy = false;
             }
             while (more) {                                            // refill
@@ -353,7 +351,7 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                     o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
                     d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
                     rb.init(S, o, d, t_min, t_max);
-                    best = t_max; bu = 0.0; bv = 0.0; prim = RT_MISS;
+                    best = t_max; prim = RT_MISS;
                     cur = S.root; sp = 0;
                 }
                 chunk_pos += take;
@@ -408,7 +406,10 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                 const D3 e1 = mk(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
                 const D3 e2 = mk(mkd(r.x, r.y), mkd(r.z, r.w), mkd(e.x, e.y));
                 double t, u, v;
-                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) { best = t; prim = e.z; bu = u; bv = v; rb.nearest(best); }
+                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) {
+                    best = t; prim = e.z; rb.nearest(best);
+                    hb.bu[slot] = u; hb.bv[slot] = v;
+                }
             } else {                                                  // SphGeom: c, r, rot2 (7 doubles), prim
                 const D3 sc = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
                 const double sr = mkd(b.z, b.w);
