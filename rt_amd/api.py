@@ -265,18 +265,38 @@ class SceneDesc:
             mat_ids[id(m)] = len(mats) - 1
             return mat_ids[id(m)]
 
+        from .importers import TriangleSoup             # arrays of triangles (importers): flattened without a loop
         sph = [s for s in shapes if isinstance(s, Sphere)]
-        tri = [t for t in shapes if isinstance(t, Triangle)]
+        tri = [t for t in shapes if isinstance(t, (Triangle, TriangleSoup))]
         if len(sph) + len(tri) != len(shapes):
-            raise TypeError("shapes must be Sphere or Triangle")
+            raise TypeError("shapes must be Sphere, Triangle or TriangleSoup")
         S = np.zeros(len(sph), _abi.sphere_dt)
         for i, s in enumerate(sph):
             S[i]["center"], S[i]["radius"], S[i]["face"], S[i]["material"] = s.center, s.radius, s.front_direction, mat_id(s.material)
-        T = np.zeros(len(tri), _abi.triangle_dt)
-        for i, t in enumerate(tri):
-            T[i]["a"], T[i]["b"], T[i]["c"] = t.a, t.b, t.c
-            T[i]["uv"] = (t.uv_a, t.uv_b, t.uv_c)
-            T[i]["n"], T[i]["material"] = t.normal, mat_id(t.material)
+        parts = []
+        single = []
+
+        def flush_single():
+            if single:
+                T1 = np.zeros(len(single), _abi.triangle_dt)
+                for i, t in enumerate(single):
+                    T1[i]["a"], T1[i]["b"], T1[i]["c"] = t.a, t.b, t.c
+                    T1[i]["uv"] = (t.uv_a, t.uv_b, t.uv_c)
+                    T1[i]["n"], T1[i]["material"] = t.normal, mat_id(t.material)
+                parts.append(T1)
+                single.clear()
+
+        for t in tri:
+            if isinstance(t, Triangle):
+                single.append(t)
+                continue
+            flush_single()
+            Tn = np.zeros(len(t), _abi.triangle_dt)
+            Tn["a"], Tn["b"], Tn["c"], Tn["uv"], Tn["n"] = t.a, t.b, t.c, t.uv, t.normal
+            Tn["material"] = mat_id(t.material)
+            parts.append(Tn)
+        flush_single()
+        T = np.concatenate(parts) if parts else np.zeros(0, _abi.triangle_dt)
         M = np.array(mats, dtype=_abi.material_dt) if mats else np.zeros(0, _abi.material_dt)
         X = np.array(texs, dtype=_abi.texture_dt) if texs else np.zeros(0, _abi.texture_dt)
         return SceneDesc(S, T, M, X, np.frombuffer(bytes(pool), dtype=np.uint8).copy(), sky)

@@ -355,3 +355,28 @@ def test_sample_grouping_of_camera_waves_does_not_change_the_image(monkeypatch, 
     a = odd.render_image(world, spp=50, seed=2)
     monkeypatch.setenv("RT_HIP_GROUP", "1")
     assert np.array_equal(a, odd.render_image(world, spp=50, seed=2))
+
+
+def test_obj_import_to_closest_hits(tmp_path, oracle):
+    """f3 end to end: an OBJ file -> load_obj -> World.build -> closest hits, against the oracle on the same
+    flattened scene."""
+    from rt_amd import importers
+    rng = np.random.default_rng(4)
+    n = 24
+    gx, gy = np.meshgrid(np.linspace(-4, 4, n), np.linspace(-4, 4, n), indexing="ij")
+    gz = 0.6 * np.sin(gx) * np.cos(1.3 * gy) + 0.05 * rng.standard_normal(gx.shape)
+    lines = ["o terrain"] + [f"v {x:.6f} {y:.6f} {z:.6f}" for x, y, z in zip(gx.ravel(), gy.ravel(), gz.ravel())]
+    for i in range(n - 1):
+        for j in range(n - 1):
+            v = i * n + j + 1
+            lines.append(f"f {v} {v + n} {v + n + 1} {v + 1}")            # quads: fan-triangulated by the loader
+    path = tmp_path / "terrain.obj"
+    path.write_text("\n".join(lines) + "\n")
+    soups = importers.load_obj(str(path), Lambertian.new_rgb_solid(0.6, 0.5, 0.4))
+    assert len(soups) == 1 and len(soups[0]) == 2 * (n - 1) * (n - 1)
+    desc = SceneDesc.from_shapes(soups + [Sphere((0.0, 0.0, 2.0), 0.7, Lambertian.new_rgb_solid(0.2, 0.2, 0.8))])
+    world, orc = World.build(desc), oracle.OracleScene(desc)
+    rays = random_rays(20_000, 41, -4.0, 4.0)
+    gpu = world.hit(rays)
+    assert_hits_equal(gpu, orc.hit(rays, mode=oracle.BRUTE))
+    assert (gpu["prim"] != _abi.RT_MISS).mean() > 0.2
