@@ -168,6 +168,8 @@ typedef struct rt_scene_info {
     uint32_t node_bytes, tri_bytes, sphere_bytes;   /* per-record sizes of the HBM layout (node: the one bounce rays traverse) */
     uint32_t bvh_width;                             /* children per node of that structure: 2 or 4 */
     double build_seconds, upload_seconds;
+    uint32_t builder;                               /* 0: binned SAH on the host; 1: Morton-order build on the device (RT_HIP_BUILDER=lbvh) */
+    uint32_t _pad;
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 

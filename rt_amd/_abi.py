@@ -44,7 +44,7 @@ hit_dt = np.dtype([("t", "<f8"), ("prim", "<u4"), ("_pad", "<u4")])
 scene_info_dt = np.dtype([("n_prims", "<u8"), ("n_nodes", "<u8"), ("device_bytes", "<u8"),
                           ("bvh_depth", "<u4"), ("max_leaf_size", "<u4"), ("node_bytes", "<u4"),
                           ("tri_bytes", "<u4"), ("sphere_bytes", "<u4"), ("bvh_width", "<u4"),
-                          ("build_seconds", "<f8"), ("upload_seconds", "<f8")])
+                          ("build_seconds", "<f8"), ("upload_seconds", "<f8"), ("builder", "<u4"), ("_pad", "<u4")])
 # oracle-only record (oracle/rt_oracle.h)
 isect_dt = np.dtype([("point", "<f8", 3), ("normal", "<f8", 3), ("uv", "<f8", 2), ("t", "<f8"),
                      ("prim", "<u4"), ("material", "<u4"), ("front", "<i4"), ("_pad", "<i4")])
@@ -54,7 +54,7 @@ EXPECTED_SIZES = {
     "rt_sphere": (sphere_dt, 64), "rt_triangle": (triangle_dt, 152), "rt_material": (material_dt, 32),
     "rt_texture": (texture_dt, 64), "rt_sky": (sky_dt, 144), "rt_camera": (camera_dt, 184),
     "rt_opts": (opts_dt, 40), "rt_stats": (stats_dt, 104), "rt_ray": (ray_dt, 48), "rt_hit": (hit_dt, 16),
-    "rt_scene_info": (scene_info_dt, 64),
+    "rt_scene_info": (scene_info_dt, 72),
 }
 for _name, (_dt, _size) in EXPECTED_SIZES.items():
     assert _dt.itemsize == _size, (_name, _dt.itemsize, _size)

@@ -3,6 +3,7 @@
 // homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= BVH_MAX_DEPTH.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "rt_layout.h"
@@ -23,6 +24,11 @@ struct BvhResult {
 
 // boxes: first n_spheres entries are spheres, the rest triangles (the caller's primitive order).
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out);
+
+// The same result from the device (bvh_gpu.hip: Morton order, Karras radix tree, bottom-up fit; leaf collapse and
+// depth-first renumbering on the host).  Returns 0 = ok; > 0 = not applicable (tiny scene, tree deeper than
+// BVH_MAX_DEPTH): use build_bvh; < 0 = error, message in err.  Needs a current HIP device.
+int build_bvh_device(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, std::string& err);
 
 // f32 copy of the nodes with boxes rounded outward.
 void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out);

@@ -22,7 +22,7 @@
 static_assert(sizeof(rt_sphere) == 64 && sizeof(rt_triangle) == 152 && sizeof(rt_material) == 32 &&
                   sizeof(rt_texture) == 64 && sizeof(rt_sky) == 144 && sizeof(rt_camera) == 184 &&
                   sizeof(rt_opts) == 40 && sizeof(rt_stats) == 104 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
-                  sizeof(rt_scene_info) == 64,
+                  sizeof(rt_scene_info) == 72,
               "ABI struct sizes (mirrored in rt_amd/_abi.py)");
 
 using namespace rt;
@@ -111,6 +111,7 @@ struct rt_scene {
     std::vector<void*> allocs;
     rt_scene_info info{};
     std::mutex mu;
+    bool device_built = false;       // BVH from bvh_gpu.hip
     Workspace ws[2];                 // one per in-flight pass (two passes are pipelined)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_acc[2] = {nullptr, nullptr};
@@ -523,7 +524,18 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             }
         }
         BvhResult bvh;
-        build_bvh(boxes, n_spheres, bvh);
+        // RT_HIP_BUILDER=lbvh: Morton-order build on the device (milliseconds; lower tree quality); default: binned SAH
+        // on the host.  The device build declines tiny scenes and trees deeper than the traversal stacks.
+        const char* be = getenv("RT_HIP_BUILDER");
+        bool built = false;
+        if (be && strcmp(be, "lbvh") == 0) {
+            std::string berr;
+            const int brc = build_bvh_device(boxes, n_spheres, bvh, berr);
+            if (brc < 0) return fail(RT_ERR_HIP, "device BVH build: %s", berr.c_str());
+            built = brc == 0;
+        }
+        sc->device_built = built;
+        if (!built) build_bvh(boxes, n_spheres, bvh);
         if (bvh.depth > (uint32_t)BVH_MAX_DEPTH)
             return fail(RT_ERR_LIMIT, "internal: BVH depth %u exceeds the traversal stack (%d)", bvh.depth, BVH_MAX_DEPTH);
         if (bvh.tri_order.size() != n_triangles || bvh.sph_order.size() != n_spheres)
@@ -663,6 +675,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.max_leaf_size = bvh.max_leaf;
         sc->info.node_bytes = use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
         sc->info.bvh_width = use4 ? 4 : 2;
+        sc->info.builder = sc->device_built ? 1u : 0u;
         (void)n_nodes4;
         sc->info.tri_bytes = sizeof(TriGeom);
         sc->info.sphere_bytes = sizeof(SphGeom);

@@ -380,3 +380,27 @@ def test_obj_import_to_closest_hits(tmp_path, oracle):
     gpu = world.hit(rays)
     assert_hits_equal(gpu, orc.hit(rays, mode=oracle.BRUTE))
     assert (gpu["prim"] != _abi.RT_MISS).mean() > 0.2
+
+
+def test_device_bvh_builder_gives_the_same_hits(monkeypatch, oracle):
+    """f1: RT_HIP_BUILDER=lbvh builds the tree on the device (Morton order, Karras radix tree, bottom-up fit).
+    Another tree, the same closest hits and the same image."""
+    scenes_ = {"mixed": scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40), "heightfield": scenes.heightfield_scene(quads=96)}
+    for name, desc in scenes_.items():
+        host = World.build(desc)
+        monkeypatch.setenv("RT_HIP_BUILDER", "lbvh")
+        dev = World.build(desc)
+        monkeypatch.delenv("RT_HIP_BUILDER")
+        hi, di = host.info(), dev.info()
+        assert (hi["builder"], di["builder"]) == (0, 1), name
+        assert di["bvh_depth"] <= 32 and di["max_leaf_size"] <= 4 and di["n_prims"] == hi["n_prims"]
+        lo, hi_ = (-45.0, 45.0) if name == "heightfield" else (-8.0, 8.0)
+        rays = np.concatenate([random_rays(30_000, 51, lo, hi_), degenerate_rays(desc, 3)])
+        got = dev.hit(rays)
+        assert_hits_equal(got, host.hit(rays))
+        assert_hits_equal(got, oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
+        cam = scenes.heightfield_camera(160, 90) if name == "heightfield" else Camera.new((9.0, -7.0, 4.0), (0.0, 0.0, 0.8), (0.0, 0.0, 1.0), 10.0, 0.3, 96, 64, 4, 12, 35.0)
+        assert np.array_equal(cam.render_image(dev, spp=4, seed=2), cam.render_image(host, spp=4, seed=2)), name
+    monkeypatch.setenv("RT_HIP_BUILDER", "lbvh")                      # tiny scenes are declined: host builder
+    tiny = World.build(SceneDesc.from_shapes([Sphere((0.0, 0.0, 0.0), 1.0, Lambertian.new_rgb_solid(0.5, 0.5, 0.5))]))
+    assert tiny.info()["builder"] == 0
