@@ -310,10 +310,11 @@ bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, Qua
 }
 
 namespace {
+template <class NodeT>
 struct Wide {
     const std::vector<Node64>& in;
     const QuantGrid& g;
-    std::vector<Node4>& out;
+    std::vector<NodeT>& out;
     bool ok = true;
     struct Ent { uint32_t ref; double lo[3], hi[3]; };
     long double dec(uint32_t q, int k) const { return (long double)g.origin[k] + (long double)q * (long double)g.cell[k]; }   // exact plane
@@ -374,7 +375,10 @@ struct Wide {
             deepest = std::max(deepest, emit(e[i].ref, ci));
             refs[i] = ci;
         }
-        Node4& nd = out[index];
+        store(out[index], e, c, refs);
+        return (uint32_t)(c - 1) + deepest;
+    }
+    void store(Node4& nd, const Ent* e, int c, const uint32_t* refs) {
         for (int i = 0; i < 4; ++i) {
             nd.child[i] = refs[i];
             for (int k = 0; k < 3; ++k) {
@@ -382,7 +386,16 @@ struct Wide {
                 nd.box[i][3 + k] = i < c ? qhi(e[i].hi[k], k) : (uint16_t)0;
             }
         }
-        return (uint32_t)(c - 1) + deepest;
+    }
+    void store(Node4f& nd, const Ent* e, int c, const uint32_t* refs) {
+        for (int i = 0; i < 4; ++i) {
+            nd.child[i] = refs[i];
+            nd._pad[i] = 0;
+            for (int k = 0; k < 3; ++k) {
+                nd.box[i][k] = i < c ? round_down(e[i].lo[k]) : INFINITY;
+                nd.box[i][3 + k] = i < c ? round_up(e[i].hi[k]) : -INFINITY;
+            }
+        }
     }
 };
 }  // namespace
@@ -391,10 +404,23 @@ bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vect
     if (in.empty()) return false;
     std::vector<Node4> res;
     res.reserve(in.size() / 2 + 16);
-    Wide w{in, grid, res};
+    Wide<Node4> w{in, grid, res};
     uint32_t root = 0;
     stack_need = w.emit(0, root);
     if (!w.ok || root != 0) return false;
+    out.swap(res);
+    return true;
+}
+
+bool widen_nodes_f32(const std::vector<Node64>& in, std::vector<Node4f>& out, uint32_t& stack_need) {
+    if (in.empty()) return false;
+    std::vector<Node4f> res;
+    res.reserve(in.size() / 2 + 16);
+    const QuantGrid none{};
+    Wide<Node4f> w{in, none, res};
+    uint32_t root = 0;
+    stack_need = w.emit(0, root);
+    if (root != 0) return false;
     out.swap(res);
     return true;
 }

@@ -42,5 +42,7 @@ bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, Qua
 // entries a near-first traversal that pushes every other hit child can hold at once, worst case.
 // Returns false when a box cannot be represented on the grid.
 bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<Node4>& out, uint32_t& stack_need);
+// the same with f32 boxes rounded outward (no grid needed; the caller has checked that coordinates fit f32)
+bool widen_nodes_f32(const std::vector<Node64>& in, std::vector<Node4f>& out, uint32_t& stack_need);
 
 }  // namespace rt

@@ -622,8 +622,9 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->d.nodes32 = nullptr;
         sc->d.nodes16 = nullptr;
         sc->d.nodes4 = nullptr;
+        sc->d.nodes4f = nullptr;
         sc->d.stack4 = 0;
-        bool use16 = false, use4 = false;
+        bool use16 = false, use4 = false, use4f = false;
         size_t n_nodes4 = 0;
         if (use32) {
             std::vector<Node32> n32;
@@ -651,6 +652,19 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                             use4 ? "used" : "not used");
                 }
             }
+            // no usable grid: the BVH4 with f32 boxes (RT_HIP_NODE_BOXES=f32 keeps the BVH2 for A/B, =w4f forces this one)
+            const bool force4f = nb && strcmp(nb, "w4f") == 0;
+            if ((!use16 && !no16) || force4f) {
+                std::vector<Node4f> n4f;
+                uint32_t need = 0;
+                if (widen_nodes_f32(bvh.nodes, n4f, need) && need <= (uint32_t)BVH4_MAX_STACK) {
+                    if ((rc = upload(sc, n4f, &sc->d.nodes4f))) return rc;
+                    sc->d.nodes4 = nullptr;
+                    sc->d.stack4 = need;
+                    use4 = true;
+                    use4f = true;
+                }
+            }
         } else {
             if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
         }
@@ -673,7 +687,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.n_nodes = bvh.nodes.size();
         sc->info.bvh_depth = bvh.depth;
         sc->info.max_leaf_size = bvh.max_leaf;
-        sc->info.node_bytes = use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
+        sc->info.node_bytes = use4f ? sizeof(Node4f) : use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
         sc->info.bvh_width = use4 ? 4 : 2;
         sc->info.builder = sc->device_built ? 1u : 0u;
         (void)n_nodes4;

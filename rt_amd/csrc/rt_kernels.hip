@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "rt_device.h"
 
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
 // one.  A step fetches one 64-byte node, tests its four child boxes in grid space (Box16), sorts the hit
 // children by entry distance (5 compare-exchanges), descends into the nearest and pushes the others
 // far-to-near: half the node fetches and dependent steps of the BVH2 walk per ray.  The box tests only
-// cull and the primitive tests are the same exact f64 ones, so (prim, t) do not change.
+// cull and the primitive tests are the same exact f64 ones, so (prim, t) do not change.  BoxT = Box32 walks the
+// f32 variant of the tree (Node4f, 128-byte nodes, world space) for scenes without a usable grid.
 // Lane refill: wave p owns the 64-entry chunks p, p + P, p + 2P, ... (P = gridDim.x) of the queue.  When
 // RT_REFILL_T or more lanes are idle and chunks are left, the finished lanes store their hits and take the
 // next rays.  Launched with P = number of chunks it is the plain one-chunk-per-wave kernel; launched with
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
 #else
 #define RT_T4_ATTR
 #endif
-template <bool STATS, int STACK>
+template <class BoxT, bool STATS, int STACK>
 __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace4(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
                                                                          HitBuf hb, unsigned long long* counters) {
     __shared__ uint32_t stack[STACK][TRACE_BLOCK];
@@ -318,7 +320,8 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
     bool busy = false;                                                // this lane holds a ray
     uint32_t slot = 0;
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
-    Box16 rb;
+    constexpr bool F32_NODES = std::is_same<BoxT, Box32>::value;      // Node4f (128 B) instead of Node4 (64 B)
+    BoxT rb;
     rb.init(S, o, d, t_min, t_max);
     double best = t_max;                                              // (barycentrics go to hb when a hit is accepted:
     uint32_t prim = RT_MISS;                                          //  four registers fewer across the loop)
@@ -367,24 +370,31 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         // issued before anything waits, whatever mix of node and leaf lanes the wave holds.
         const uint32_t first = cur & REF_FIRST_MASK;
         const bool tri_leaf = at_leaf && !(cur & REF_SPHERE);
-        const char* src = at_node ? reinterpret_cast<const char*>(&S.nodes4[cur])
+        const char* src = at_node ? (F32_NODES ? reinterpret_cast<const char*>(&S.nodes4f[cur]) : reinterpret_cast<const char*>(&S.nodes4[cur]))
                                   : tri_leaf ? reinterpret_cast<const char*>(&S.tris[first]) : reinterpret_cast<const char*>(&S.sphs[first]);
         const uint4* p = reinterpret_cast<const uint4*>(src);
-        uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
         if (at_node || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
-        if (tri_leaf) e = p[4];
+        if (tri_leaf || (F32_NODES && at_node)) e = p[4];
+        if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
         if (at_node) {
             if (STATS) ++n_nodes;
-            const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            const uint32_t w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
+                                    r.x, r.y, r.z, r.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
             uint32_t ref[4] = {r.x, r.y, r.z, r.w};
+            if (F32_NODES) { ref[0] = g.x; ref[1] = g.y; ref[2] = g.z; ref[3] = g.w; }
             float key[4];
             int n_hit = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
-                const uint32_t w0 = w[3 * k], w1 = w[3 * k + 1], w2 = w[3 * k + 2];
-                const float lo[3] = {(float)(w0 & 0xFFFFu), (float)(w0 >> 16), (float)(w1 & 0xFFFFu)};
-                const float hi[3] = {(float)(w1 >> 16), (float)(w2 & 0xFFFFu), (float)(w2 >> 16)};
+                float lo[3], hi[3];
+                if (F32_NODES) {          // child k owns floats 6k .. 6k+5
+                    for (int j = 0; j < 3; ++j) { lo[j] = __uint_as_float(w[6 * k + j]); hi[j] = __uint_as_float(w[6 * k + 3 + j]); }
+                } else {                  // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
+                    const uint32_t w0 = w[3 * k], w1 = w[3 * k + 1], w2 = w[3 * k + 2];
+                    lo[0] = (float)(w0 & 0xFFFFu); lo[1] = (float)(w0 >> 16); lo[2] = (float)(w1 & 0xFFFFu);
+                    hi[0] = (float)(w1 >> 16); hi[1] = (float)(w2 & 0xFFFFu); hi[2] = (float)(w2 >> 16);
+                }
                 float tn = 0.f;
                 const bool h = ref[k] != REF_EMPTY && rb.test(lo, hi, tn);
                 key[k] = h ? (tn < 3.0e38f ? tn : 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
@@ -991,31 +1001,36 @@ void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, con
 #undef RT_LAUNCH_PACKET
 }
 
-template <int STACK>
+template <class BoxT, int STACK>
 static void launch_trace4_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                             unsigned long long* d_counters, hipStream_t s) {
     // persistent (one wave per hardware slot, lanes refilled) once the queue holds several chunks per slot
-    static const unsigned slots_plain = resident_waves(k_trace4<false, STACK>);
-    static const unsigned slots_stats = resident_waves(k_trace4<true, STACK>);
+    static const unsigned slots_plain = resident_waves(k_trace4<BoxT, false, STACK>);
+    static const unsigned slots_stats = resident_waves(k_trace4<BoxT, true, STACK>);
     const unsigned slots = refill_slots(stats ? slots_stats : slots_plain);
     const bool persist = refill4_enabled() && qm.n_waves >= 2u * slots;
     const dim3 grid(persist ? slots : qm.n_waves), block(TRACE_BLOCK);
     if (stats)
-        hipLaunchKernelGGL((k_trace4<true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+        hipLaunchKernelGGL((k_trace4<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
     else
-        hipLaunchKernelGGL((k_trace4<false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+        hipLaunchKernelGGL((k_trace4<BoxT, false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+}
+template <class BoxT>
+static void launch_trace4_t(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
+                            unsigned long long* d_counters, hipStream_t s) {
+    if (S.stack4 <= 16) launch_trace4_s<BoxT, 16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.stack4 <= 24) launch_trace4_s<BoxT, 24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.stack4 <= 32) launch_trace4_s<BoxT, 32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.stack4 <= 48) launch_trace4_s<BoxT, 48>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else launch_trace4_s<BoxT, BVH4_MAX_STACK>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }
 
 void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                   unsigned long long* d_counters, hipStream_t s) {
     if (!qm.n_waves) return;
-    if (S.nodes4 && S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
-        if (S.stack4 <= 16) launch_trace4_s<16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        else if (S.stack4 <= 24) launch_trace4_s<24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        else if (S.stack4 <= 32) launch_trace4_s<32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        else if (S.stack4 <= 48) launch_trace4_s<48>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        else launch_trace4_s<BVH4_MAX_STACK>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-        return;
+    if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
+        if (S.nodes4) { launch_trace4_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s); return; }
+        if (S.nodes4f) { launch_trace4_t<Box32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s); return; }
     }
     if (S.nodes16)
         launch_trace_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);

@@ -65,6 +65,15 @@ struct alignas(64) Node4 {
 static_assert(sizeof(Node4) == 64, "Node4 layout");
 constexpr int BVH4_MAX_STACK = 64;   // widest per-lane stack a kernel instance provides
 
+// The same BVH4 with f32 boxes (rounded outward) for scenes whose 16-bit grid would be too coarse (a huge
+// ground plane next to small spheres): one 128-byte line per node.
+struct alignas(128) Node4f {
+    float box[4][6];         // child k: lo x, y, z, hi x, y, z
+    uint32_t child[4];
+    uint32_t _pad[4];
+};
+static_assert(sizeof(Node4f) == 128, "Node4f layout");
+
 // Triangle geometry in leaf order: a, e1 = b - a, e2 = c - a (src/hittable.rs:412-413), f64.
 struct alignas(16) TriGeom {
     double a[3], e1[3], e2[3];
@@ -115,6 +124,7 @@ struct DScene {
     const Node32* nodes32;
     const Node16* nodes16;       // optional (null when quantisation would inflate the leaves too much)
     const Node4* nodes4;         // optional: BVH4 over the same leaves, same grid (per-lane traversal prefers it)
+    const Node4f* nodes4f;       // optional: BVH4 with f32 boxes, when there is no grid
     const TriGeom* tris;
     const SphGeom* sphs;
     const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres
@@ -126,8 +136,8 @@ struct DScene {
     uint32_t root;               // REF_EMPTY for an empty scene, else 0
     uint32_t bvh_depth;          // deepest child reference = traversal stack entries needed
     QuantGrid grid;              // of nodes16 and nodes4
-    uint32_t stack4;             // traversal stack entries nodes4 needs in the worst case
-    uint32_t _pad2[3];
+    uint32_t stack4;             // traversal stack entries nodes4 / nodes4f need in the worst case
+    uint32_t _pad2[1];
     rt_sky sky;
 };
 

@@ -256,18 +256,19 @@ def test_node_formats_agree(monkeypatch, oracle):
     grid is fine enough).  Boxes only cull: all formats must give the same hits and the same image, bit for bit."""
     desc = scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40)
     worlds = {}
-    for fmt in ("w4", "q16", "f32", "f64"):
+    for fmt in ("w4", "w4f", "q16", "f32", "f64"):
         monkeypatch.setenv("RT_HIP_NODE_BOXES", fmt)
         worlds[fmt] = World.build(desc)
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
     worlds["default"] = World.build(desc)
-    assert [worlds[f].info()["node_bytes"] for f in ("w4", "q16", "f32", "f64")] == [64, 32, 64, 128]
-    assert [worlds[f].info()["bvh_width"] for f in ("default", "w4", "q16", "f32", "f64")] == [4, 4, 2, 2, 2]
+    assert [worlds[f].info()["node_bytes"] for f in ("w4", "w4f", "q16", "f32", "f64")] == [64, 128, 32, 64, 128]
+    assert [worlds[f].info()["bvh_width"] for f in ("default", "w4", "w4f", "q16", "f32", "f64")] == [4, 4, 4, 2, 2, 2]
     rays = np.concatenate([random_rays(40_000, 17), degenerate_rays(desc, 6)])
     hits = {f: w.hit(rays) for f, w in worlds.items()}
     assert_hits_equal(hits["f32"], hits["f64"])
     assert_hits_equal(hits["q16"], hits["f64"])
     assert_hits_equal(hits["w4"], hits["f64"])
+    assert_hits_equal(hits["w4f"], hits["f64"])
     assert_hits_equal(hits["default"], hits["f64"])
     assert_hits_equal(hits["q16"], oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
     # on ordinary rays the wider margins / coarser boxes accept only a few extra nodes
@@ -279,13 +280,15 @@ def test_node_formats_agree(monkeypatch, oracle):
     assert np.array_equal(cam.render_image(worlds["f32"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["q16"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["w4"], spp=3, seed=2), img)
+    assert np.array_equal(cam.render_image(worlds["w4f"], spp=3, seed=2), img)
 
 
 def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypatch, cover, oracle):
     """The cover scene's 10000-unit ground plane makes the 16-bit grid coarser than the spheres: the
-    library keeps f32 nodes there; forcing the grid must still be conservative (same hits)."""
+    library keeps f32 boxes there (as a BVH4 with 128-byte nodes); forcing the grid must still be conservative
+    (same hits)."""
     desc, world, orc = cover
-    assert world.info()["node_bytes"] == 64
+    assert world.info()["node_bytes"] == 128 and world.info()["bvh_width"] == 4
     monkeypatch.setenv("RT_HIP_NODE_BOXES", "q16")
     forced = World.build(desc)
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
