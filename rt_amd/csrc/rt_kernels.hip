@@ -447,129 +447,6 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
     }
 }
 
-// K1r — the same traversal in PERSISTENT waves with lane refill.  Bounce rays end after very different
-// numbers of steps (sky escapes after a dozen nodes, grazing rays after a hundred), so in k_trace a wave
-// runs at the pace of its longest ray with about a third of its lanes busy.  Here the launch is one wave
-// per hardware slot; wave p owns the 64-entry chunks p, p + P, p + 2P, ... of the queue, and whenever
-// RT_REFILL_T or more lanes are idle the finished lanes store their hits and take the next rays of the
-// wave's chunks.  Every ray still runs exactly k_trace's own traversal, so (prim, t) do not change.
-// Every wave exits: chunks are consumed monotonically and the loop ends when none is left and no lane
-// holds a ray.
-#ifndef RT_REFILL_T
-#define RT_REFILL_T 24
-#endif
-template <class BoxT, bool STATS, int STACK>
-__global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace_refill(DScene S, RayQueue q, QueueMap qm, double t_min,
-                                                                               double t_max, HitBuf hb, unsigned long long* counters) {
-    __shared__ uint32_t stack[STACK][TRACE_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = qm.n_waves, stride = gridDim.x;
-    uint32_t next_chunk = blockIdx.x, chunk = 0, chunk_pos = 64;      // wave-uniform
-    bool busy = false;                                                // this lane holds a ray
-    uint32_t slot = 0;
-    D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
-    BoxT rb;
-    rb.init(S, o, d, t_min, t_max);
-    double best = t_max, bu = 0.0, bv = 0.0;
-    uint32_t prim = RT_MISS;
-    uint32_t cur = REF_EMPTY;
-    int sp = 0;
-    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
-
-    for (;;) {
-        const bool at_node = !(cur & REF_LEAF);
-        const bool at_leaf = !at_node && cur != REF_EMPTY;
-        const unsigned long long m_live = __ballot(at_node || at_leaf);
-        bool more = chunk_pos < 64u || next_chunk < n_chunks;
-        if (!m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T)) {
-            if (busy && cur == REF_EMPTY) {                           // retire
-                hb.t[slot] = prim == RT_MISS ? 0.0 : best;
-                hb.prim[slot] = prim;
-                hb.bu[slot] = bu;
-                hb.bv[slot] = bv;
-                busy = false;
-            }
-            while (more) {                                            // refill
-                const unsigned long long m_idle = __ballot(!busy);
-                if (!m_idle) break;
-                if (chunk_pos >= 64u) {
-                    chunk = next_chunk; next_chunk += stride; chunk_pos = 0;
-                }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                const uint32_t take = min((uint32_t)__popcll(m_idle), 64u - chunk_pos);
-                uint32_t i = 0;
-                if (!busy && rank < take && queue_slot(qm, chunk, chunk_pos + rank, i)) {
-                    slot = i; busy = true;
-                    o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
-                    d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
-                    rb.init(S, o, d, t_min, t_max);
-                    best = t_max; bu = 0.0; bv = 0.0; prim = RT_MISS;
-                    cur = S.root; sp = 0;
-                }
-                chunk_pos += take;
-                more = chunk_pos < 64u || next_chunk < n_chunks;
-            }
-            if (!__ballot(busy)) break;
-            continue;
-        }
-        if (STATS) ++n_iters;
-        if (at_node) {
-            typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
-            uint32_t cl, cr;
-            rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
-            if (STATS) ++n_nodes;
-            bool hl = rb.test(lo_l, hi_l, tl);
-            bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                stack[sp++][tid] = left_first ? cr : cl;
-                cur = left_first ? cl : cr;
-            } else if (hl) {
-                cur = cl;
-            } else if (hr) {
-                cur = cr;
-            } else {
-                cur = sp ? stack[--sp][tid] : REF_EMPTY;
-            }
-        }
-        if (at_leaf) {
-            const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
-            if (STATS) { n_prims += count; ++n_leaves; }
-            if (cur & REF_SPHERE) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const SphGeom* g = &S.sphs[first + k];
-                    double t;
-                    if (sph_test(ld3(g->c), g->r, ld3(g->rot2), o, d, t_min, best, t)) { best = t; prim = g->prim; rb.nearest(best); }
-                }
-            } else {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const TriGeom* g = &S.tris[first + k];
-                    double t, u, v;
-                    if (tri_test(ld3(g->a), ld3(g->e1), ld3(g->e2), o, d, t_min, best, t, u, v)) {
-                        best = t; prim = g->prim; bu = u; bv = v;
-                        rb.nearest(best);
-                    }
-                }
-            }
-            cur = sp ? stack[--sp][tid] : REF_EMPTY;
-        }
-    }
-    if (STATS) {
-        unsigned long long a = n_nodes, b = n_prims, c = n_leaves;
-        for (int off = 32; off; off >>= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-            c += __shfl_xor(c, off);
-        }
-        if ((tid & 63u) == 0) {
-            atomicAdd(&counters[0], a);
-            atomicAdd(&counters[1], b);
-            atomicAdd(&counters[4], (unsigned long long)n_iters);     // wave loop iterations (debug: lane utilisation)
-            atomicAdd(&counters[5], c);                               // leaf visits
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1p — closest hit for COHERENT waves (camera rays of an 8x8 pixel tile): packet traversal.
 // The wave walks the BVH once: the current node, the stack and the loop are wave-uniform, nodes
@@ -933,37 +810,13 @@ static unsigned resident_waves(K kernel) {
         return 256u * 8u;
     return (unsigned)pr.multiProcessorCount * (unsigned)per_cu;
 }
-// Measured on the 1 M-triangle frame: refill raises the loop-level lane occupancy from 0.45 to 0.80 and cuts
-// the wave iterations by 43 %, yet the bounce launches take 13 % LONGER (89 vs 79 ms per frame): the kernel is
-// bound by the per-lane rate of the memory pipe (tools/micro/gather_bench.hip), not by issue slots, and the
-// persistent form holds 4 instead of 5 waves per SIMD.  So it is opt-in: RT_HIP_REFILL=1 (RT_HIP_NO_REFILL=1
-// overrides); RT_HIP_REFILL_SLOTS=<n> sets the number of persistent waves (tests use a handful to exercise
-// many refills on small inputs).  Read per launch.
-static bool refill_enabled() {
-    const char* e = getenv("RT_HIP_REFILL");
-    const char* n = getenv("RT_HIP_NO_REFILL");
-    return e && atoi(e) == 1 && !(n && atoi(n) == 1);
-}
 // the BVH4 kernel refills by default (RT_HIP_NO_REFILL=1 launches it one chunk per wave)
 static bool refill4_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); return !(n && atoi(n) == 1); }
 static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
 template <class BoxT, int STACK>
 static void launch_trace_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
                            unsigned long long* d_counters, hipStream_t s) {
-    const dim3 block(TRACE_BLOCK);
-    // persistent waves with lane refill once the queue holds several chunks per hardware slot
-    static const unsigned slots_plain = resident_waves(k_trace_refill<BoxT, false, STACK>);
-    static const unsigned slots_stats = resident_waves(k_trace_refill<BoxT, true, STACK>);
-    const unsigned slots = refill_slots(stats ? slots_stats : slots_plain);
-    if (refill_enabled() && qm.n_waves >= 2u * slots) {
-        const dim3 grid(slots);
-        if (stats)
-            hipLaunchKernelGGL((k_trace_refill<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-        else
-            hipLaunchKernelGGL((k_trace_refill<BoxT, false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-        return;
-    }
-    const dim3 grid(qm.n_waves);
+    const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
     if (stats)
         hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
     else

@@ -323,8 +323,9 @@ def test_persistent_refill_kernel_is_bit_exact(monkeypatch, cover, mixed, oracle
     one-chunk-per-wave kernel: a few persistent waves over many ragged chunks, then a render through it."""
     desc, world, orc = mixed
     rays = random_rays(30_011, 77)                       # 469 chunks, the last one ragged
+    monkeypatch.setenv("RT_HIP_NO_REFILL", "1")
     plain = world.hit(rays)
-    monkeypatch.setenv("RT_HIP_REFILL", "1")                # opt-in: slower than the plain kernel on MI355X
+    monkeypatch.delenv("RT_HIP_NO_REFILL")
     for slots in (1, 7, 64):
         monkeypatch.setenv("RT_HIP_REFILL_SLOTS", str(slots))
         got = world.hit(rays)
