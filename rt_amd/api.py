@@ -48,8 +48,18 @@ def _scale(a, s):
     return (a[0] * s, a[1] * s, a[2] * s)
 
 
+def _fdiv(x, s):
+    """IEEE division like Rust's f64 (0/0 = NaN, x/0 = +-inf): a zero-area triangle gets a NaN normal, not an exception."""
+    try:
+        return x / s
+    except ZeroDivisionError:
+        if x == 0.0 or x != x:
+            return math.nan
+        return math.copysign(math.inf, x) * math.copysign(1.0, s)
+
+
 def _div(a, s):
-    return (a[0] / s, a[1] / s, a[2] / s)
+    return (_fdiv(a[0], s), _fdiv(a[1], s), _fdiv(a[2], s))
 
 
 def _cross(a, b):

@@ -408,3 +408,33 @@ def test_device_bvh_builder_gives_the_same_hits(monkeypatch, oracle):
     monkeypatch.setenv("RT_HIP_BUILDER", "lbvh")                      # tiny scenes are declined: host builder
     tiny = World.build(SceneDesc.from_shapes([Sphere((0.0, 0.0, 0.0), 1.0, Lambertian.new_rgb_solid(0.5, 0.5, 0.5))]))
     assert tiny.info()["builder"] == 0
+
+
+def test_degenerate_scenes_and_rays_terminate_and_match(monkeypatch, oracle):
+    """Coincident primitives (every split is degenerate: median fallback, deep trees), zero-area triangles and rays
+    with a zero / NaN / infinite direction: no hang, no fault, and the same answers as the oracle (t only where
+    coincident primitives tie)."""
+    mat = Lambertian.new_rgb_solid(0.5, 0.5, 0.5)
+    tri = lambda z: Triangle((-1.0, -1.0, z), (1.0, -1.0, z), (0.0, 1.0, z), mat)
+    shapes = [tri(0.0) for _ in range(3000)] + [Sphere((0.0, 0.0, 2.0), 0.5, mat) for _ in range(500)]
+    shapes += [Triangle((0.0, 0.0, 1.0), (0.0, 0.0, 1.0), (0.0, 0.0, 1.0), mat),          # a point
+               Triangle((0.0, 0.0, 1.0), (1.0, 1.0, 1.0), (2.0, 2.0, 1.0), mat)]          # a segment
+    desc = SceneDesc.from_shapes(shapes)
+    orc = oracle.OracleScene(desc)
+    rays = random_rays(4000, 61, -1.5, 1.5)
+    rays[:, 2] = 4.0
+    rays[:, 5] = -np.abs(rays[:, 5]) - 0.2
+    weird = np.array([[0, 0, 4, 0, 0, 0], [0, 0, 4, np.nan, 0, -1], [0, 0, 4, 0, 0, -np.inf], [np.nan, 0, 4, 0, 0, -1],
+                      [0, 0, 4, 0, 0, -1], [0.25, 0.1, 4, 0, 0, -1]], dtype=np.float64)
+    rays = np.concatenate([rays, weird])
+    ref = orc.hit(rays, mode=oracle.BRUTE)
+    for builder in ("sah", "lbvh"):
+        monkeypatch.setenv("RT_HIP_BUILDER", builder)
+        world = World.build(desc)
+        assert world.info()["bvh_depth"] <= 32
+        got = world.hit(rays)
+        assert np.array_equal(got["t"], ref["t"]), builder
+        assert np.array_equal(got["prim"] == _abi.RT_MISS, ref["prim"] == _abi.RT_MISS), builder
+        cam = Camera.new((0.0, -6.0, 3.0), (0.0, 0.0, 0.5), (0.0, 0.0, 1.0), 6.0, 0.0, 64, 48, 2, 8, 40.0)
+        img = cam.render_image(world, spp=2, seed=1)
+        assert np.isfinite(img).all()
