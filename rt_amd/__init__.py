@@ -8,7 +8,7 @@ loudly if it is missing.
 """
 from . import _abi  # noqa: F401
 from .api import (Camera, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal, SceneDesc,  # noqa: F401
-                  SolidColor, Sphere, Triangle, World, encode_gamma8, generate_ground_plane, write_ppm)
+                  SolidColor, Sphere, Triangle, World, encode_gamma8, generate_ground_plane, write_png, write_ppm)
 
 __all__ = ["Camera", "World", "Sphere", "Triangle", "Lambertian", "Metal", "Dielectric", "SolidColor",
-           "CheckerTexture", "ImageTexture", "SceneDesc", "generate_ground_plane", "encode_gamma8", "write_ppm"]
+           "CheckerTexture", "ImageTexture", "SceneDesc", "generate_ground_plane", "encode_gamma8", "write_ppm", "write_png"]

@@ -469,3 +469,22 @@ def write_ppm(path, rgb8):
         f.write(f"P3\n{w} {h} # width, height\n255 # max color value\n")
         for y in range(h):
             f.write(" ".join(f"{r} {g} {b}" for r, g, b in rgb8[y]) + "\n")
+
+
+def write_png(path, rgb8):
+    """The same 8-bit frame as a PNG (the reference only writes ASCII PPM): 8-bit RGB, filter 0,
+    one zlib stream; stdlib only."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("write_png expects (H, W, 3) uint8")
+    h, w = img.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

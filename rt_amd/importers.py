@@ -256,14 +256,54 @@ def material_from_gltf(doc, buffers, base, material_index):
     return Metal.new_solid((color[0], color[1], color[2]), fuzz)
 
 
-def load_gltf(file_path, _mesh_material=None):
-    """load_gltf (src/hittable.rs:556-633) -> [TriangleSoup per primitive that has indices and positions]."""
+def _node_world_matrices(doc):
+    """mesh index -> [4x4 world matrix of every node of the default scene that instantiates it] (column-vector
+    convention, parent * local; local = matrix or T * R * S)."""
+    nodes = doc.get("nodes", [])
+
+    def local(n):
+        if "matrix" in n:
+            return np.array(n["matrix"], dtype=np.float64).reshape(4, 4).T        # glTF stores column-major
+        t = np.array(n.get("translation", [0, 0, 0]), dtype=np.float64)
+        x, y, z, w = np.array(n.get("rotation", [0, 0, 0, 1]), dtype=np.float64)
+        sc = np.array(n.get("scale", [1, 1, 1]), dtype=np.float64)
+        r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        m = np.eye(4)
+        m[:3, :3] = r * sc
+        m[:3, 3] = t
+        return m
+
+    scenes_ = doc.get("scenes", [])
+    roots = scenes_[doc.get("scene", 0)]["nodes"] if scenes_ else list(range(len(nodes)))
+    out = {}
+    stack = [(i, np.eye(4)) for i in roots]
+    seen = 0
+    while stack:
+        i, parent = stack.pop()
+        seen += 1
+        if seen > 4 * len(nodes) + 4:
+            raise ValueError("glTF node graph is not a tree")
+        m = parent @ local(nodes[i])
+        if "mesh" in nodes[i]:
+            out.setdefault(nodes[i]["mesh"], []).append(m)
+        stack.extend((c, m) for c in nodes[i].get("children", []))
+    return out
+
+
+def load_gltf(file_path, _mesh_material=None, apply_node_transforms=False):
+    """load_gltf (src/hittable.rs:556-633) -> [TriangleSoup per primitive that has indices and positions].
+    apply_node_transforms=True is an extension (SURVEY §8 f3 "honour node transforms"): every instance of a mesh in
+    the default scene is emitted with its node's world matrix applied to the positions (as points); the default
+    mirrors the reference, which reads `gltf.meshes()` and ignores the scene graph."""
     try:
         doc, buffers, base = _load_document(file_path)
     except (OSError, ValueError, KeyError) as e:
         raise ValueError(f"gltf loader failed to read {file_path}") from e
     meshes = []
-    for mesh in doc.get("meshes", []):
+    world = _node_world_matrices(doc) if apply_node_transforms else {}
+    for mesh_index, mesh in enumerate(doc.get("meshes", [])):
         for prim in mesh.get("primitives", []):
             material = material_from_gltf(doc, buffers, base, prim.get("material"))
             attrs = prim.get("attributes", {})
@@ -282,5 +322,10 @@ def load_gltf(file_path, _mesh_material=None):
             tri = indices[: len(indices) // 3 * 3].reshape(-1, 3)       # chunks_exact(3)
             p = positions.astype(np.float64)
             uv = tc.astype(np.float64)[tri]                             # (n, 3, 2)
-            meshes.append(TriangleSoup(p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]], material, uv))
+            if not apply_node_transforms:
+                meshes.append(TriangleSoup(p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]], material, uv))
+                continue
+            for m in world.get(mesh_index, []):
+                pw = p @ m[:3, :3].T + m[:3, 3]
+                meshes.append(TriangleSoup(pw[tri[:, 0]], pw[tri[:, 1]], pw[tri[:, 2]], material, uv))
     return meshes

@@ -156,3 +156,25 @@ def test_soups_flatten_like_triangle_lists(tmp_path):
     assert len(fast.triangles) == 5 and len(fast.spheres) == 1
     assert fast.triangles.tobytes() == slow.triangles.tobytes()
     assert fast.materials.tobytes() == slow.materials.tobytes()
+
+
+def test_gltf_node_transforms_are_an_opt_in_extension(tmp_path):
+    path = make_gltf(tmp_path, with_texture=False)
+    doc = json.loads(open(path).read())
+    doc["nodes"] = [{"children": [1], "translation": [100, 0, 0]}, {"mesh": 0, "scale": [2, 2, 2], "rotation": [0, 0, 0.7071067811865476, 0.7071067811865476]}]
+    doc["scenes"] = [{"nodes": [0]}]
+    p = tmp_path / "n.gltf"
+    p.write_text(json.dumps(doc))
+    plain = importers.load_gltf(str(p))[0]
+    assert np.array_equal(plain.b[0], [1, 0, 0])
+    moved = importers.load_gltf(str(p), apply_node_transforms=True)[0]
+    assert np.allclose(moved.b[0], [100, 2, 0])            # (1,0,0): x2, rotated 90 degrees about z, then +100 in x
+    assert np.allclose(moved.a[0], [100, 0, 0])
+
+
+def test_write_png_round_trip(tmp_path):
+    from PIL import Image as PILImage
+    from rt_amd import write_png
+    img = (np.arange(5 * 7 * 3) * 37 % 256).astype(np.uint8).reshape(5, 7, 3)
+    write_png(str(tmp_path / "o.png"), img)
+    assert np.array_equal(np.asarray(PILImage.open(tmp_path / "o.png").convert("RGB")), img)
