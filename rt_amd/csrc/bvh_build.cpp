@@ -80,7 +80,7 @@ struct Builder {
     }
 
     // Builds the subtree over idx[first, first+count); returns its child reference (which sits at
-    // `depth`) and its bounds.  Invariant: ceil_log2(count) <= BVH_MAX_DEPTH - depth.
+    // `depth`) and its bounds.  Invariant: ceil_log2(count) <= SAH_MAX_DEPTH - depth.
     uint32_t build(size_t first, size_t count, int depth, Box& bounds) {
         Box cb;
         bounds = Box();
@@ -134,7 +134,7 @@ struct Builder {
         }
 
         // --- partition
-        const int remaining = BVH_MAX_DEPTH - depth;   // levels available below this reference
+        const int remaining = SAH_MAX_DEPTH - depth;   // levels available below this reference
         size_t mid = first;
         if (best_axis >= 0) {
             double c0 = cb.lo[best_axis], scale = NBINS / (cb.hi[best_axis] - cb.lo[best_axis]);

@@ -1,6 +1,6 @@
 // bvh_build.h — host BVH builder for the flattened scene (replaces bvh::Bvh::build_par, which the
 // reference calls at src/hittable.rs:34).  Binned SAH, BVH2 with child boxes in the parent,
-// homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= BVH_MAX_DEPTH.
+// homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= SAH_MAX_DEPTH.
 #pragma once
 #include <cstdint>
 #include <string>

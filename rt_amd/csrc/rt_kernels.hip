@@ -831,6 +831,8 @@ static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, doub
         launch_trace_s<BoxT, 16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else if (S.bvh_depth <= 24)
         launch_trace_s<BoxT, 24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+    else if (S.bvh_depth <= 32)
+        launch_trace_s<BoxT, 32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
     else
         launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
 }

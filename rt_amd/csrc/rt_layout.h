@@ -17,8 +17,10 @@ constexpr uint32_t REF_SPHERE = 0x40000000u;
 constexpr uint32_t REF_FIRST_MASK = 0x0FFFFFFFu;
 constexpr int MAX_LEAF = 4;
 // Traversal keeps one pending entry per ancestor, so the per-lane LDS stack needs `depth` entries;
-// the builder guarantees every child reference sits at depth <= BVH_MAX_DEPTH.
-constexpr int BVH_MAX_DEPTH = 32;
+// the kernels provide stacks for child references down to depth BVH_MAX_DEPTH.  The host SAH builder keeps its
+// trees within SAH_MAX_DEPTH (median-split fallback); Morton-order trees from the device builder may be deeper.
+constexpr int BVH_MAX_DEPTH = 64;
+constexpr int SAH_MAX_DEPTH = 32;
 
 // BVH2 node with both child boxes in the parent, f64 bounds: one 128-byte line per node.
 struct alignas(128) Node64 {
