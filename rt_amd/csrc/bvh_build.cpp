@@ -2,8 +2,11 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -41,14 +44,26 @@ inline int ceil_log2(size_t n) {
     return l;
 }
 
-struct Builder {
+// Subtrees of at most `task_threshold` primitives are built by worker threads: the top of the tree is built
+// first and records them as tasks (placeholder references), the workers build each into its own BvhResult, and
+// build_bvh stitches them in task order (deterministic, whatever the thread timing).
+constexpr uint32_t TASK_REF = 0x70000000u;               // placeholder: TASK_REF | task index (node indices stay below)
+struct Task {
+    size_t first = 0, count = 0;
+    int depth = 0;
+    uint32_t parent = 0;
+    int side = 0;                                         // 0: parent's left, 1: right
+    Box bounds;
+    uint32_t ref = REF_EMPTY;
+    BvhResult result;
+};
+
+struct Shared {
     const std::vector<PrimBox>& pb;
     size_t nsph;
     std::vector<uint32_t> idx;
     std::vector<double> cent;   // 3 per prim
-    BvhResult& out;
-
-    Builder(const std::vector<PrimBox>& b, size_t ns, BvhResult& o) : pb(b), nsph(ns), out(o) {
+    Shared(const std::vector<PrimBox>& b, size_t ns) : pb(b), nsph(ns) {
         idx.resize(b.size());
         cent.resize(3 * b.size());
         for (size_t i = 0; i < b.size(); ++i) {
@@ -56,6 +71,18 @@ struct Builder {
             for (int k = 0; k < 3; ++k) cent[3 * i + k] = 0.5 * (b[i].lo[k] + b[i].hi[k]);
         }
     }
+};
+
+struct Builder {
+    const std::vector<PrimBox>& pb;
+    size_t nsph;
+    std::vector<uint32_t>& idx;     // shared; a builder only touches its own range
+    const std::vector<double>& cent;
+    BvhResult& out;
+    std::vector<Task>* tasks = nullptr;
+    size_t task_threshold = 0;
+
+    Builder(Shared& sh, BvhResult& o) : pb(sh.pb), nsph(sh.nsph), idx(sh.idx), cent(sh.cent), out(o) {}
 
     bool homogeneous(size_t first, size_t count) const {
         bool s0 = idx[first] < nsph;
@@ -82,6 +109,12 @@ struct Builder {
     // Builds the subtree over idx[first, first+count); returns its child reference (which sits at
     // `depth`) and its bounds.  Invariant: ceil_log2(count) <= SAH_MAX_DEPTH - depth.
     uint32_t build(size_t first, size_t count, int depth, Box& bounds) {
+        if (tasks && depth > 0 && count <= task_threshold) {
+            Task t;
+            t.first = first; t.count = count; t.depth = depth;
+            tasks->push_back(std::move(t));
+            return TASK_REF | (uint32_t)(tasks->size() - 1);
+        }
         Box cb;
         bounds = Box();
         for (size_t i = first; i < first + count; ++i) {
@@ -163,6 +196,10 @@ struct Builder {
         Box bl, br;
         uint32_t l = build(first, nl, depth + 1, bl);
         uint32_t r = build(mid, nr, depth + 1, br);
+        if (tasks) {
+            if ((l & 0xF0000000u) == TASK_REF) { (*tasks)[l & 0x0FFFFFFFu].parent = me; (*tasks)[l & 0x0FFFFFFFu].side = 0; }
+            if ((r & 0xF0000000u) == TASK_REF) { (*tasks)[r & 0x0FFFFFFFu].parent = me; (*tasks)[r & 0x0FFFFFFFu].side = 1; }
+        }
         Node64& n = out.nodes[me];
         for (int k = 0; k < 3; ++k) {
             n.lo_l[k] = bl.lo[k]; n.hi_l[k] = bl.hi[k];
@@ -189,6 +226,13 @@ inline float round_up(double x) {
 
 }  // namespace
 
+static unsigned build_threads() {
+    const char* e = getenv("RT_HIP_BUILD_THREADS");
+    if (e && atoi(e) > 0) return (unsigned)atoi(e);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out) {
     out = BvhResult();
     const size_t n = boxes.size();
@@ -196,7 +240,8 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
     out.nodes.reserve(n / 2 + 16);
     out.tri_order.reserve(n - n_spheres);
     out.sph_order.reserve(n_spheres);
-    Builder B(boxes, n_spheres, out);
+    Shared sh(boxes, n_spheres);
+    Builder B(sh, out);
     Box bounds;
     // Probe: would the whole scene be a single leaf?  Then wrap it so that node 0 always exists.
     bool single = n == 1 || (n <= (size_t)RT_LEAF_MAX && B.homogeneous(0, n));
@@ -215,7 +260,56 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
         for (uint32_t& p : nd._pad) p = 0;
         return;
     }
+    const unsigned T = build_threads();
+    std::vector<Task> tasks;
+    if (T > 1 && n >= 200000) {
+        B.tasks = &tasks;
+        B.task_threshold = std::max<size_t>(4096, n / ((size_t)T * 8));
+    }
     uint32_t root = B.build(0, n, 0, bounds);
+    if (!tasks.empty()) {
+        // workers take tasks from a shared counter; every task writes only its own Task and its own idx range
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= tasks.size()) return;
+                Task& t = tasks[k];
+                t.result.nodes.reserve(t.count / 2 + 16);
+                Builder b(sh, t.result);
+                t.ref = b.build(t.first, t.count, t.depth, t.bounds);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < T; ++i) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+        // stitch in task order
+        for (Task& t : tasks) {
+            const uint32_t node_base = (uint32_t)out.nodes.size(), tri_base = (uint32_t)out.tri_order.size(),
+                           sph_base = (uint32_t)out.sph_order.size();
+            auto fix = [&](uint32_t ref) -> uint32_t {
+                if (ref == REF_EMPTY) return ref;
+                if (ref & REF_LEAF) return ref + ((ref & REF_SPHERE) ? sph_base : tri_base);     // `first` sits in the low bits
+                return ref + node_base;
+            };
+            for (Node64 nd : t.result.nodes) {
+                nd.left = fix(nd.left);
+                nd.right = fix(nd.right);
+                out.nodes.push_back(nd);
+            }
+            out.tri_order.insert(out.tri_order.end(), t.result.tri_order.begin(), t.result.tri_order.end());
+            out.sph_order.insert(out.sph_order.end(), t.result.sph_order.begin(), t.result.sph_order.end());
+            out.depth = std::max(out.depth, t.result.depth);
+            out.max_leaf = std::max(out.max_leaf, t.result.max_leaf);
+            Node64& par = out.nodes[t.parent];
+            double* lo = t.side ? par.lo_r : par.lo_l;
+            double* hi = t.side ? par.hi_r : par.hi_l;
+            for (int k = 0; k < 3; ++k) { lo[k] = t.bounds.lo[k]; hi[k] = t.bounds.hi[k]; }
+            (t.side ? par.right : par.left) = fix(t.ref);
+            t.result = BvhResult();
+        }
+    }
     if (root & REF_LEAF) {
         // count in (1, MAX_LEAF] and SAH preferred a leaf: cannot happen (handled by `single`),
         // kept for safety.
