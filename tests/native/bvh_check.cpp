@@ -1,0 +1,131 @@
+// Host-only check of the BVH builders' CPU code (bvh_build.cpp): builds trees over random boxes — sequentially and
+// with worker threads — and validates them: every primitive in exactly one leaf, leaves homogeneous and <= MAX_LEAF,
+// every child box encloses its subtree, depth within SAH_MAX_DEPTH, f32 / u16 / BVH4 copies conservative.
+// Compiled by tests/test_bvh_host.py with g++ -fsanitize=address,undefined (no GPU, no HIP).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../rt_amd/csrc/bvh_build.h"
+
+using namespace rt;
+
+struct B3 { double lo[3], hi[3]; };
+static int fails = 0;
+#define CHECK(c, ...) do { if (!(c)) { if (fails++ < 10) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+static B3 walk(const BvhResult& r, const std::vector<PrimBox>& boxes, size_t n_spheres, uint32_t ref, int depth,
+               std::vector<int>& seen, uint32_t& max_depth) {
+    B3 b = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+    max_depth = std::max(max_depth, (uint32_t)depth);
+    if (ref & REF_LEAF) {
+        const uint32_t first = ref & REF_FIRST_MASK, count = ((ref >> 28) & 3u) + 1u;
+        const bool sph = ref & REF_SPHERE;
+        CHECK(count <= (uint32_t)MAX_LEAF, "leaf of %u", count);
+        for (uint32_t k = 0; k < count; ++k) {
+            const size_t order_size = sph ? r.sph_order.size() : r.tri_order.size();
+            CHECK(first + k < order_size, "leaf range beyond the order array");
+            if (first + k >= order_size) break;
+            const uint32_t p = sph ? r.sph_order[first + k] : r.tri_order[first + k] + (uint32_t)n_spheres;
+            seen[p]++;
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::fmin(b.lo[a], boxes[p].lo[a]); b.hi[a] = std::fmax(b.hi[a], boxes[p].hi[a]); }
+        }
+        return b;
+    }
+    CHECK(ref < r.nodes.size(), "node index %u of %zu", ref, r.nodes.size());
+    const Node64& nd = r.nodes[ref];
+    B3 l = walk(r, boxes, n_spheres, nd.left, depth + 1, seen, max_depth);
+    for (int a = 0; a < 3; ++a) CHECK(nd.lo_l[a] <= l.lo[a] && nd.hi_l[a] >= l.hi[a], "left box of node %u does not enclose", ref);
+    b = l;
+    if (nd.right != REF_EMPTY) {
+        B3 rr = walk(r, boxes, n_spheres, nd.right, depth + 1, seen, max_depth);
+        for (int a = 0; a < 3; ++a) {
+            CHECK(nd.lo_r[a] <= rr.lo[a] && nd.hi_r[a] >= rr.hi[a], "right box of node %u does not enclose", ref);
+            b.lo[a] = std::fmin(b.lo[a], rr.lo[a]); b.hi[a] = std::fmax(b.hi[a], rr.hi[a]);
+        }
+    }
+    return b;
+}
+
+static size_t last_nodes = 0;
+static uint32_t last_depth = 0;
+static void check_tree(const char* what, const std::vector<PrimBox>& boxes, size_t n_spheres) {
+    BvhResult r;
+    build_bvh(boxes, n_spheres, r);
+    last_nodes = r.nodes.size();
+    last_depth = r.depth;
+    std::vector<int> seen(boxes.size(), 0);
+    uint32_t max_depth = 0;
+    if (!boxes.empty()) walk(r, boxes, n_spheres, 0, 0, seen, max_depth);
+    size_t bad = 0;
+    for (int s : seen) bad += s != 1;
+    CHECK(bad == 0, "%s: %zu primitives not in exactly one leaf", what, bad);
+    CHECK(max_depth <= (uint32_t)SAH_MAX_DEPTH && r.depth <= (uint32_t)SAH_MAX_DEPTH && max_depth == r.depth, "%s: depth %u (recorded %u)", what, max_depth, r.depth);
+    CHECK(r.tri_order.size() == boxes.size() - n_spheres && r.sph_order.size() == n_spheres, "%s: order sizes", what);
+    // derived node formats stay conservative
+    std::vector<Node32> n32;
+    narrow_nodes(r.nodes, n32);
+    for (size_t i = 0; i < r.nodes.size(); ++i)
+        for (int a = 0; a < 3; ++a) {
+            CHECK((double)n32[i].lo_l[a] <= r.nodes[i].lo_l[a] && (double)n32[i].hi_l[a] >= r.nodes[i].hi_l[a], "%s: f32 left box", what);
+            if (r.nodes[i].right != REF_EMPTY)
+                CHECK((double)n32[i].lo_r[a] <= r.nodes[i].lo_r[a] && (double)n32[i].hi_r[a] >= r.nodes[i].hi_r[a], "%s: f32 right box", what);
+        }
+    std::vector<Node16> n16;
+    QuantGrid g;
+    if (!n32.empty() && quantize_nodes(n32, n16, g, 1e300)) {
+        for (size_t i = 0; i < n32.size(); ++i)
+            for (int a = 0; a < 3; ++a) {
+                const long double lo = (long double)g.origin[a] + (long double)n16[i].lo_l[a] * g.cell[a];
+                const long double hi = (long double)g.origin[a] + (long double)n16[i].hi_l[a] * g.cell[a];
+                CHECK(lo <= n32[i].lo_l[a] && hi >= n32[i].hi_l[a], "%s: u16 left box of node %zu axis %d", what, i, a);
+            }
+        std::vector<Node4> n4;
+        uint32_t need = 0;
+        CHECK(widen_nodes(r.nodes, g, n4, need), "%s: widen_nodes failed", what);
+        size_t leaves = 0;
+        for (const Node4& nd : n4)
+            for (int k = 0; k < 4; ++k) {
+                if (nd.child[k] == REF_EMPTY) continue;
+                if (nd.child[k] & REF_LEAF) leaves += ((nd.child[k] >> 28) & 3u) + 1u; else CHECK(nd.child[k] < n4.size(), "%s: BVH4 child index", what);
+            }
+        CHECK(leaves == boxes.size(), "%s: BVH4 holds %zu of %zu primitives", what, leaves, boxes.size());
+        CHECK(need <= 3u * (r.depth + 1), "%s: BVH4 stack need %u", what, need);
+    }
+    std::vector<Node4f> n4f;
+    uint32_t need_f = 0;
+    if (!r.nodes.empty()) CHECK(widen_nodes_f32(r.nodes, n4f, need_f), "%s: widen_nodes_f32 failed", what);
+    printf("%-28s n=%8zu nodes=%8zu depth=%2u max_leaf=%u\n", what, boxes.size(), r.nodes.size(), r.depth, r.max_leaf);
+}
+
+int main() {
+    std::mt19937_64 rng(42);
+    std::uniform_real_distribution<double> U(-100.0, 100.0), S(0.01, 2.0);
+    auto random_boxes = [&](size_t n) {
+        std::vector<PrimBox> b(n);
+        for (auto& p : b)
+            for (int a = 0; a < 3; ++a) { const double c = U(rng), e = S(rng); p.lo[a] = c - e; p.hi[a] = c + e; }
+        return b;
+    };
+    check_tree("empty", {}, 0);
+    check_tree("one sphere", random_boxes(1), 1);
+    check_tree("three triangles", random_boxes(3), 0);
+    check_tree("mixed small", random_boxes(37), 11);
+    check_tree("mixed 50k (sequential)", random_boxes(50000), 7000);
+    {   // coincident primitives: every SAH split is degenerate
+        std::vector<PrimBox> b(5000, random_boxes(1)[0]);
+        check_tree("5000 coincident", b, 100);
+    }
+    const std::vector<PrimBox> big = random_boxes(300000);
+    setenv("RT_HIP_BUILD_THREADS", "4", 1);
+    check_tree("mixed 300k (4 threads)", big, 20000);
+    const size_t nodes4 = last_nodes;
+    const uint32_t depth4 = last_depth;
+    setenv("RT_HIP_BUILD_THREADS", "1", 1);
+    check_tree("mixed 300k (1 thread)", big, 20000);
+    CHECK(nodes4 == last_nodes && depth4 == last_depth, "threaded build differs from the sequential one: %zu/%u vs %zu/%u", nodes4, depth4, last_nodes, last_depth);
+    printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+}
