@@ -167,12 +167,35 @@ struct Box32 {
 // per node.  The builder checks in exact arithmetic that origin + q*cell encloses every box.
 struct Box16 : Box32 {
     using Node = Node16;
+    // byte selectors for v_perm_b32: out of the three words of a Node4 child they build (near16 | far16 << 16) for
+    // each axis, near = lo when the ray runs in +axis direction, hi otherwise
+    uint32_t sx, sy, sz;
     __device__ __forceinline__ void init(const DScene& S, D3 o, D3 d, double t_min, double t_max) {
         lo_t = f32_below(t_min); hi_t = f32_above(t_max);
         const double cx = (double)S.grid.cell[0], cy = (double)S.grid.cell[1], cz = (double)S.grid.cell[2];
         set_axis((o.x - (double)S.grid.origin[0]) / cx, cx / d.x, ix, nx, fx);
         set_axis((o.y - (double)S.grid.origin[1]) / cy, cy / d.y, iy, ny, fy);
         set_axis((o.z - (double)S.grid.origin[2]) / cz, cz / d.z, iz, nz, fz);
+        sx = ix < 0.f ? 0x01000706u : 0x07060100u;      // lo.x = w0[15:0],  hi.x = w1[31:16]   (perm(w1, w0))
+        sy = iy < 0.f ? 0x03020504u : 0x05040302u;      // lo.y = w0[31:16], hi.y = w2[15:0]    (perm(w2, w0))
+        sz = iz < 0.f ? 0x01000706u : 0x07060100u;      // lo.z = w1[15:0],  hi.z = w2[31:16]   (perm(w2, w1))
+    }
+    // The slab test on one Node4 child (words w0, w1, w2) without min/max: the near and far plane of each axis are
+    // picked by the sign of the direction (one v_perm_b32 per axis), then one fma per plane.  Same error budget as
+    // Box32::test (the planes and the roundings are the same ones); a NaN (ray parallel to the slab) drops out of
+    // fmaxf/fminf or reaches the negated comparisons, which accept.
+    __device__ __forceinline__ bool test_child(uint32_t w0, uint32_t w1, uint32_t w2, float& t_near) const {
+        const float r = 0x1.0p-22f;
+        const uint32_t px = __builtin_amdgcn_perm(w1, w0, sx), py = __builtin_amdgcn_perm(w2, w0, sy), pz = __builtin_amdgcn_perm(w2, w1, sz);
+        const float ax = fmaf((float)(px & 0xFFFFu), ix, nx), bx = fmaf((float)(px >> 16), ix, fx);
+        const float ay = fmaf((float)(py & 0xFFFFu), iy, ny), by = fmaf((float)(py >> 16), iy, fy);
+        const float az = fmaf((float)(pz & 0xFFFFu), iz, nz), bz = fmaf((float)(pz >> 16), iz, fz);
+        float tn = fmaxf(fmaxf(ax, ay), az);
+        float tf = fminf(fminf(bx, by), bz);
+        tn = fmaf(-fabsf(tn), r, tn);
+        tf = fmaf(fabsf(tf), r, tf);
+        t_near = tn;
+        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
     }
     __device__ __forceinline__ void fetch(const DScene& S, uint32_t cur, float* lo_l, float* hi_l, float* lo_r, float* hi_r,
                                           uint32_t& cl, uint32_t& cr) const {
@@ -387,17 +410,16 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             int n_hit = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo[3], hi[3];
-                if (F32_NODES) {          // child k owns floats 6k .. 6k+5
-                    for (int j = 0; j < 3; ++j) { lo[j] = __uint_as_float(w[6 * k + j]); hi[j] = __uint_as_float(w[6 * k + 3 + j]); }
-                } else {                  // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
-                    const uint32_t w0 = w[3 * k], w1 = w[3 * k + 1], w2 = w[3 * k + 2];
-                    lo[0] = (float)(w0 & 0xFFFFu); lo[1] = (float)(w0 >> 16); lo[2] = (float)(w1 & 0xFFFFu);
-                    hi[0] = (float)(w1 >> 16); hi[1] = (float)(w2 & 0xFFFFu); hi[2] = (float)(w2 >> 16);
-                }
                 float tn = 0.f;
-                const bool h = ref[k] != REF_EMPTY && rb.test(lo, hi, tn);
-                key[k] = h ? (tn < 3.0e38f ? tn : 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
+                bool h;
+                if constexpr (F32_NODES) {          // child k owns floats 6k .. 6k+5
+                    float lo[3], hi[3];
+                    for (int j = 0; j < 3; ++j) { lo[j] = __uint_as_float(w[6 * k + j]); hi[j] = __uint_as_float(w[6 * k + 3 + j]); }
+                    h = ref[k] != REF_EMPTY && rb.test(lo, hi, tn);
+                } else {                            // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
+                    h = ref[k] != REF_EMPTY && rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
+                }
+                key[k] = h ? fminf(tn, 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
                 n_hit += h ? 1 : 0;
             }
 #define RT_CE(x, y) { const bool sw = key[y] < key[x]; const float kx = sw ? key[y] : key[x], ky = sw ? key[x] : key[y]; \
