@@ -106,11 +106,13 @@ def pmc_traffic(workload):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                           "*_traffic_%s.json" % workload.replace("_", ""))))
     if not files:
-        return None, None, None
+        return None, None, None, None
     k = json.load(open(files[-1]))["kernels"]
-    pick = lambda pre: next((v["traffic_bytes_per_launch"] for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
-                             if n.startswith(pre)), None)
-    return (pick("k_trace4<") or pick("k_trace<")), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1])
+    pick = lambda pre, key="traffic_bytes_per_launch": next((v.get(key) for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
+                                                             if n.startswith(pre)), None)
+    valu = {"k_trace4": pick("k_trace4<", "valu_active_per_simd_cycle"), "k_trace_packet": pick("k_trace_packet", "valu_active_per_simd_cycle"),
+            "k_shade": pick("k_shade", "valu_active_per_simd_cycle")}
+    return (pick("k_trace4<") or pick("k_trace<")), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
 
 
 def main():
@@ -217,7 +219,7 @@ def main():
         a_on = min(1.0, (s_seg - s_pseg) / max(1, s_pseg))
         p_bytes_per_seg = 24 * (1 - a_on) + 76 * a_on + pv_n * 64 + pv_p * prim_bytes
         p_achieved = prim_seg * p_bytes_per_seg / prim_s / 1e9 if prim_s > 0 else 0.0
-        traffic, p_traffic, traffic_src = pmc_traffic(args.workload)
+        traffic, p_traffic, traffic_src, valu = pmc_traffic(args.workload)
         img = rgb_mean.cpu().numpy()
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
@@ -228,7 +230,9 @@ def main():
                        "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_trace4 (per-lane BVH4 traversal of bounce segments)" if info.get("bvh_width") == 4 else "k_trace (per-lane BVH2 traversal of bounce segments)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "valu_active_per_simd_cycle": valu,        # rocprofv3 SQ_ACTIVE_INST_VALU / SIMD-cycles, same PMC summary
+                         "kernel": "k_trace4 (per-lane BVH4 traversal of bounce segments)" if info.get("bvh_width") == 4 else "k_trace (per-lane BVH2 traversal of bounce segments)",
                          "avg_launch_ms": bounce_s / max(1, bounce_launches) * 1e3, "launches": bounce_launches,
                          "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
                          "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
