@@ -414,7 +414,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         }
     }
     for (int k = 0; k < n_pipes; ++k) {
-        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 64, hipMemcpyDeviceToHost, pipes[k].s));
+        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 128, hipMemcpyDeviceToHost, pipes[k].s));
         HIPCHK(hipStreamSynchronize(pipes[k].s));
     }
     HIPCHK(hipGetLastError());
@@ -429,6 +429,12 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
                 const unsigned long long* h = pipes[k].w->h_stat;
                 fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
                         k, h[0], h[5], h[4], h[4] ? (double)(h[0] + h[5]) / (64.0 * (double)h[4]) : 0.0);
+#ifdef RT_TIMING
+                const double it = (double)h[4];
+                fprintf(stderr, "[rt_hip] pipe %d cycles per wave iteration: issue %.1f wait %.1f node %.1f prim %.1f refill %.1f; "
+                        "iterations with a node step %.3f, with a primitive step %.3f\n", k, h[8] / it, h[9] / it, h[10] / it, h[11] / it,
+                        h[12] / it, h[13] / it, h[14] / it);
+#endif
             }
         }
     if (stats) *stats = st;

@@ -351,6 +351,12 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
     uint32_t cur = REF_EMPTY;
     int sp = 0;
     uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
+#ifdef RT_TIMING
+    unsigned long long tm_issue = 0, tm_wait = 0, tm_node = 0, tm_prim = 0, tm_refill = 0, tm_n_node = 0, tm_n_prim = 0, tm_last = clock64();
+#define RT_STAMP(acc) { const unsigned long long now_ = clock64(); acc += now_ - tm_last; tm_last = now_; }
+#else
+#define RT_STAMP(acc)
+#endif
 
     for (;;) {
         const bool at_node = !(cur & REF_LEAF);                 // REF_EMPTY has the leaf bit set
@@ -383,6 +389,7 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                 chunk_pos += take;
                 more = chunk_pos < 64u || next_chunk < n_chunks;
             }
+            RT_STAMP(tm_refill)
             if (!__ballot(busy)) break;
             continue;
         }
@@ -393,13 +400,23 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         // issued before anything waits, whatever mix of node and leaf lanes the wave holds.
         const uint32_t first = cur & REF_FIRST_MASK;
         const bool tri_leaf = at_leaf && !(cur & REF_SPHERE);
-        const char* src = at_node ? (F32_NODES ? reinterpret_cast<const char*>(&S.nodes4f[cur]) : reinterpret_cast<const char*>(&S.nodes4[cur]))
-                                  : tri_leaf ? reinterpret_cast<const char*>(&S.tris[first]) : reinterpret_cast<const char*>(&S.sphs[first]);
+        // base + index * stride with the three selected separately: one multiply-add instead of three masked address paths
+        const char* base_ = at_node ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
+                                    : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
+        const uint32_t stride_ = at_node ? (uint32_t)(F32_NODES ? sizeof(Node4f) : sizeof(Node4)) : tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
+        const char* src = base_ + (uint64_t)(at_node ? cur : first) * stride_;
         const uint4* p = reinterpret_cast<const uint4*>(src);
         uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
         if (at_node || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
         if (tri_leaf || (F32_NODES && at_node)) e = p[4];
         if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
+#ifdef RT_TIMING
+        RT_STAMP(tm_issue)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RT_STAMP(tm_wait)
+        if (__ballot(at_node)) ++tm_n_node;
+        if (__ballot(at_leaf)) ++tm_n_prim;
+#endif
         if (at_node) {
             if (STATS) ++n_nodes;
             const uint32_t w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
@@ -415,9 +432,13 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                 if constexpr (F32_NODES) {          // child k owns floats 6k .. 6k+5
                     float lo[3], hi[3];
                     for (int j = 0; j < 3; ++j) { lo[j] = __uint_as_float(w[6 * k + j]); hi[j] = __uint_as_float(w[6 * k + 3 + j]); }
-                    h = ref[k] != REF_EMPTY && rb.test(lo, hi, tn);
+                    const bool hh = rb.test(lo, hi, tn);
+                    h = hh & (ref[k] != REF_EMPTY);
                 } else {                            // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
-                    h = ref[k] != REF_EMPTY && rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
+                    // all four children are tested without a branch on the empty ones (an empty slot's box is all zeros):
+                    // four masked regions per node step cost more than the arithmetic they skip
+                    const bool hh = rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
+                    h = hh & (ref[k] != REF_EMPTY);
                 }
                 key[k] = h ? fminf(tn, 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
                 n_hit += h ? 1 : 0;
@@ -431,6 +452,10 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             if (n_hit > 1) stack[sp++][tid] = ref[1];
             cur = n_hit ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
         }
+#ifdef RT_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RT_STAMP(tm_node)
+#endif
         if (at_leaf) {
             if (STATS) { ++n_prims; ++n_leaves; }
             if (tri_leaf) {                                           // TriGeom: a, e1, e2 (9 doubles), prim
@@ -452,6 +477,10 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             // next primitive of the same leaf, or pop
             cur = (cur & 0x30000000u) ? cur - 0x10000000u + 1u : (sp ? stack[--sp][tid] : REF_EMPTY);
         }
+#ifdef RT_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RT_STAMP(tm_prim)
+#endif
     }
     if (STATS) {
         unsigned long long a = n_nodes, b = n_prims, c = n_leaves;
@@ -465,6 +494,11 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             atomicAdd(&counters[1], b);
             atomicAdd(&counters[4], (unsigned long long)n_iters);
             atomicAdd(&counters[5], c);
+#ifdef RT_TIMING
+            atomicAdd(&counters[8], tm_issue); atomicAdd(&counters[9], tm_wait); atomicAdd(&counters[10], tm_node);
+            atomicAdd(&counters[11], tm_prim); atomicAdd(&counters[12], tm_refill); atomicAdd(&counters[13], tm_n_node);
+            atomicAdd(&counters[14], tm_n_prim);
+#endif
         }
     }
 }
@@ -542,8 +576,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
             const float lo_r[3] = {__uint_as_float(nd[6]), __uint_as_float(nd[7]), __uint_as_float(nd[8])};
             const float hi_r[3] = {__uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11])};
             float tl = 0.f, tr = 0.f;
-            const bool hl = mine && rb.test(lo_l, hi_l, tl);
-            const bool hr = mine && cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
+            // both boxes tested without masked regions (the node is wave-uniform, the arithmetic is per lane)
+            const bool tl_ok = rb.test(lo_l, hi_l, tl), tr_ok = rb.test(lo_r, hi_r, tr);
+            const bool hl = mine & tl_ok;
+            const bool hr = mine & tr_ok & (cr != REF_EMPTY);
             if (STATS && mine) ++n_nodes;
             const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
             if (ml && mr) {
