@@ -424,7 +424,6 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             uint32_t ref[4] = {r.x, r.y, r.z, r.w};
             if (F32_NODES) { ref[0] = g.x; ref[1] = g.y; ref[2] = g.z; ref[3] = g.w; }
             float key[4];
-            int n_hit = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float tn = 0.f;
@@ -440,17 +439,17 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                     const bool hh = rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
                     h = hh & (ref[k] != REF_EMPTY);
                 }
-                key[k] = h ? fminf(tn, 3.0e38f) : INFINITY;      // hits sort before misses, NaN/inf entry distances last among hits
-                n_hit += h ? 1 : 0;
+                key[k] = h ? tn : INFINITY;                 // misses carry no child: wherever the sort leaves them (a NaN entry
+                ref[k] = h ? ref[k] : REF_EMPTY;            // distance compares false both ways), they are skipped below
             }
 #define RT_CE(x, y) { const bool sw = key[y] < key[x]; const float kx = sw ? key[y] : key[x], ky = sw ? key[x] : key[y]; \
                       const uint32_t rx = sw ? ref[y] : ref[x], ry = sw ? ref[x] : ref[y]; key[x] = kx; key[y] = ky; ref[x] = rx; ref[y] = ry; }
             RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-            if (n_hit > 3) stack[sp++][tid] = ref[3];
-            if (n_hit > 2) stack[sp++][tid] = ref[2];
-            if (n_hit > 1) stack[sp++][tid] = ref[1];
-            cur = n_hit ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
+            if (ref[3] != REF_EMPTY) stack[sp++][tid] = ref[3];
+            if (ref[2] != REF_EMPTY) stack[sp++][tid] = ref[2];
+            if (ref[1] != REF_EMPTY) stack[sp++][tid] = ref[1];
+            cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
         }
 #ifdef RT_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
