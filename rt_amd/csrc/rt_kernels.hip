@@ -159,6 +159,19 @@ struct Box32 {
         t_near = tn;
         return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
     }
+    // The same test with the near and far plane of each axis already picked by the sign of the direction (near = lo
+    // when idf >= 0, hi otherwise): one fma per plane, no min/max per axis.  For finite planes and idf it returns what
+    // test() returns (rounding is monotone); a ray parallel to a slab gives NaN for both planes of that axis in either
+    // form, and the NaN drops out of max3 / min3 the same way.
+    __device__ __forceinline__ bool test_picked(const float* near, const float* far, float& t_near) const {
+        const float r = 0x1.0p-22f;
+        float tn = fmaxf(fmaxf(fmaf(near[0], ix, nx), fmaf(near[1], iy, ny)), fmaf(near[2], iz, nz));
+        float tf = fminf(fminf(fmaf(far[0], ix, fx), fmaf(far[1], iy, fy)), fmaf(far[2], iz, fz));
+        tn = fmaf(-fabsf(tn), r, tn);
+        tf = fmaf(fabsf(tf), r, tf);
+        t_near = tn;
+        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
+    }
 };
 
 // Box16: the same test in GRID space for nodes quantised to the global 16-bit grid (Node16, Node4): the
@@ -404,7 +417,7 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         const char* base_ = at_node ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
                                     : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
         const uint32_t stride_ = at_node ? (uint32_t)(F32_NODES ? sizeof(Node4f) : sizeof(Node4)) : tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
-        const char* src = base_ + (uint64_t)(at_node ? cur : first) * stride_;
+        const char* src = base_ + (uint64_t)first * stride_;            // (node indices are below 2^28 as well)
         const uint4* p = reinterpret_cast<const uint4*>(src);
         uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
         if (at_node || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
@@ -429,9 +442,13 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                 float tn = 0.f;
                 bool h;
                 if constexpr (F32_NODES) {          // child k owns floats 6k .. 6k+5
-                    float lo[3], hi[3];
-                    for (int j = 0; j < 3; ++j) { lo[j] = __uint_as_float(w[6 * k + j]); hi[j] = __uint_as_float(w[6 * k + 3 + j]); }
-                    const bool hh = rb.test(lo, hi, tn);
+                    const bool neg[3] = {rb.ix < 0.f, rb.iy < 0.f, rb.iz < 0.f};
+                    float near[3], far[3];
+                    for (int j = 0; j < 3; ++j) {
+                        const float lo = __uint_as_float(w[6 * k + j]), hi = __uint_as_float(w[6 * k + 3 + j]);
+                        near[j] = neg[j] ? hi : lo; far[j] = neg[j] ? lo : hi;
+                    }
+                    const bool hh = rb.test_picked(near, far, tn);
                     h = hh & (ref[k] != REF_EMPTY);
                 } else {                            // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
                     // all four children are tested without a branch on the empty ones (an empty slot's box is all zeros):
@@ -562,6 +579,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0;
     unsigned long long mask = __ballot(active);
+    // Camera rays of a few neighbouring pixels nearly always agree on the sign of each direction component; then the
+    // near and far plane of every box are the same for the whole wave and are picked with scalar selects.
+    const unsigned long long neg_x = __ballot(active && rb.ix < 0.f), neg_y = __ballot(active && rb.iy < 0.f),
+                             neg_z = __ballot(active && rb.iz < 0.f);
+    const bool same_signs = (neg_x == 0 || neg_x == mask) && (neg_y == 0 || neg_y == mask) && (neg_z == 0 || neg_z == mask);
+    const uint32_t sxn_u = __builtin_amdgcn_readfirstlane(neg_x != 0 ? 1u : 0u), syn_u = __builtin_amdgcn_readfirstlane(neg_y != 0 ? 1u : 0u),
+                   szn_u = __builtin_amdgcn_readfirstlane(neg_z != 0 ? 1u : 0u);
     uint32_t cur = (mask && S.root != REF_EMPTY) ? S.root : REF_EMPTY;
     int sp = 0;
 
@@ -576,7 +600,27 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassPara
             const float hi_r[3] = {__uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11])};
             float tl = 0.f, tr = 0.f;
             // both boxes tested without masked regions (the node is wave-uniform, the arithmetic is per lane)
-            const bool tl_ok = rb.test(lo_l, hi_l, tl), tr_ok = rb.test(lo_r, hi_r, tr);
+            bool tl_ok, tr_ok;
+            if (same_signs) {
+                // four scalar selects per axis behind one compare (the planes sit in SGPRs; written out because the
+                // compiler sets the condition code again before every select)
+                uint32_t n_l[3], f_l[3], n_r[3], f_r[3];
+#define RT_PICK(j, flag) asm("s_cmp_lg_u32 %4, 0\n\ts_cselect_b32 %0, %6, %5\n\ts_cselect_b32 %1, %5, %6\n\t" \
+                             "s_cselect_b32 %2, %8, %7\n\ts_cselect_b32 %3, %7, %8" \
+                             : "=&s"(n_l[j]), "=&s"(f_l[j]), "=&s"(n_r[j]), "=&s"(f_r[j]) \
+                             : "s"(flag), "s"(nd[j]), "s"(nd[3 + j]), "s"(nd[6 + j]), "s"(nd[9 + j]) : "scc")
+                RT_PICK(0, sxn_u); RT_PICK(1, syn_u); RT_PICK(2, szn_u);
+#undef RT_PICK
+                const float nl[3] = {__uint_as_float(n_l[0]), __uint_as_float(n_l[1]), __uint_as_float(n_l[2])};
+                const float fl[3] = {__uint_as_float(f_l[0]), __uint_as_float(f_l[1]), __uint_as_float(f_l[2])};
+                const float nr[3] = {__uint_as_float(n_r[0]), __uint_as_float(n_r[1]), __uint_as_float(n_r[2])};
+                const float fr[3] = {__uint_as_float(f_r[0]), __uint_as_float(f_r[1]), __uint_as_float(f_r[2])};
+                tl_ok = rb.test_picked(nl, fl, tl);
+                tr_ok = rb.test_picked(nr, fr, tr);
+            } else {
+                tl_ok = rb.test(lo_l, hi_l, tl);
+                tr_ok = rb.test(lo_r, hi_r, tr);
+            }
             const bool hl = mine & tl_ok;
             const bool hr = mine & tr_ok & (cr != REF_EMPTY);
             if (STATS && mine) ++n_nodes;
