@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -89,6 +90,8 @@ struct DevAllocs {
     }
 };
 
+constexpr int MAX_PIPES = 8;
+
 struct Workspace {
     size_t capacity = 0;          // paths
     char* base = nullptr;         // one device allocation, carved below
@@ -112,9 +115,9 @@ struct rt_scene {
     rt_scene_info info{};
     std::mutex mu;
     bool device_built = false;       // BVH from bvh_gpu.hip
-    Workspace ws[2];                 // one per in-flight pass (two passes are pipelined)
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_acc[2] = {nullptr, nullptr};
+    Workspace ws[MAX_PIPES];         // one per in-flight pass (DEFAULT_PIPES passes are pipelined by default)
+    hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {};
 };
 
 namespace {
@@ -220,10 +223,12 @@ int check_camera(const rt_camera* cam) {
     return RT_OK;
 }
 
-// 2^27 paths = 64 samples per pixel and pass at 1080p: 204 B of path state each, two workspaces (two passes in
-// flight) = 55 GB of the 288 GB.  Measured on the 1 M-triangle frame: 2^25 -> 4437, 2^26 -> 4658, 2^27 -> 4783 Msamples/s
-// (fewer, larger launches; tails and host round trips amortised over 4x the work).
-constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 27;
+// 2^26 paths = 32 samples per pixel and pass at 1080p: 204 B of path state each, four workspaces (four passes in
+// flight) = 55 GB of the 288 GB.  Measured on the 1 M-triangle frame (passes in flight x paths per pass, Msamples/s):
+// 2 x 2^27 5870, 3 x 2^27 6030, 4 x 2^27 6040, 3 x 2^26 6030, 4 x 2^26 6125, 6 x 2^26 6150, 4 x 2^25 6080, 8 x 2^25 6070:
+// large launches amortise the tails and host round trips, several passes in flight fill what one pass leaves idle.
+constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 26;
+constexpr int DEFAULT_PIPES = 4;
 constexpr size_t PRIMARY_MAX_PIXELS = size_t(1) << 25;
 
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
@@ -244,19 +249,21 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
     const uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
-    // Two passes are kept in flight on two streams: the tail of a pass (a dozen launches over a few
+    // Several passes are kept in flight, one stream each: the tail of a pass (a dozen launches over a few
     // thousand surviving paths, each as long as its slowest ray) and the per-bounce host round trip
-    // hide behind the other pass's bulk work.  RT_HIP_PIPES=1 disables the overlap.
+    // hide behind the other passes' bulk work.  RT_HIP_PIPES=<n> sets the number (1 disables the overlap).
     const char* pe = getenv("RT_HIP_PIPES");
-    const int n_pipes = (n_passes > 1 && !(pe && atoi(pe) == 1)) ? 2 : 1;
+    const int n_pipes = (int)std::min<uint32_t>(n_passes, pe && atoi(pe) >= 1 ? (uint32_t)std::min(atoi(pe), MAX_PIPES) : (uint32_t)DEFAULT_PIPES);
+    const bool poll_blocking = getenv("RT_HIP_BLOCKING_POLL") != nullptr;      // A/B: the round-robin blocking wait
     int rc;
     for (int k = 0; k < n_pipes; ++k)
         if ((rc = ensure_workspace(sc, npix * per_pass, k))) return rc;
-    if (n_pipes > 1 && !sc->aux_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
+    if (n_pipes > 1 && !sc->ev_fork) {
         HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    for (int k = 1; k < n_pipes; ++k)
+        if (!sc->aux_stream[k]) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
 
     PassParams pp0;
     pp0.cam = *cam;
@@ -288,14 +295,14 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         uint32_t pass = 0, nl = 0, n = 0, depth = 0;
         int cur = 0;
         enum { IDLE, RUNNING, WAIT_ACC } state = IDLE;
-    } pipes[2];
-    pipes[0].w = &sc->ws[0];
-    pipes[0].s = stream;
-    pipes[1].w = &sc->ws[1];
-    pipes[1].s = sc->aux_stream;
+    } pipes[MAX_PIPES];
+    for (int k = 0; k < n_pipes; ++k) {
+        pipes[k].w = &sc->ws[k];
+        pipes[k].s = k ? sc->aux_stream[k] : stream;
+    }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
-        HIPCHK(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
+        for (int k = 1; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
     }
     for (int k = 0; k < n_pipes; ++k)
         if (want_stats) HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, 256, pipes[k].s));
@@ -365,23 +372,36 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     };
 
     if ((rc = start_pass(pipes[0]))) return rc;
-    bool second_started = n_pipes < 2;
+    int started = 1;                 // pipes started so far: pipe k+1 starts once pipe k is past its bulk, so they stay out of phase
     while (done_passes < n_passes) {
+        bool progressed = false;
         for (int k = 0; k < n_pipes; ++k) {
             Pipe& P = pipes[k];
             if (P.state == Pipe::IDLE) {
-                // the second pipe starts once the first is past its bulk, so the two stay out of phase
-                if (next_pass < n_passes && (k == 0 || second_started)) {
+                if (next_pass < n_passes && k < started) {
                     if ((rc = start_pass(P))) return rc;
+                    progressed = true;
                 }
                 continue;
             }
             if (P.state == Pipe::WAIT_ACC) {
-                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
+                if (P.pass == next_acc) {
+                    if ((rc = accumulate(P, k))) return rc;
+                    progressed = true;
+                }
                 continue;
             }
             Workspace& w = *P.w;
-            HIPCHK(hipEventSynchronize(w.ev[4]));
+            // With two pipes the host must not sleep on one pipe's long bounce while the other pipe's short tail bounces
+            // finish one after the other: each pipe is polled, and served as soon as its bounce is done.
+            if (n_pipes > 1 && !poll_blocking) {
+                const hipError_t qe = hipEventQuery(w.ev[4]);
+                if (qe == hipErrorNotReady) continue;
+                if (qe != hipSuccess) HIPCHK(qe);
+            } else {
+                HIPCHK(hipEventSynchronize(w.ev[4]));
+            }
+            progressed = true;
             HIPCHK(hipGetLastError());
             float ms_t = 0.f, ms_s = 0.f;
             HIPCHK(hipEventElapsedTime(&ms_t, w.ev[2], w.ev[3]));
@@ -401,9 +421,9 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             P.qm = queue_map_from_counts(P.ob, w.h_count, &P.n);
             P.cur ^= 1;
             P.depth++;
-            if (!second_started && (P.depth >= 2 || P.n == 0)) {
-                second_started = true;
-                if (next_pass < n_passes && (rc = start_pass(pipes[1]))) return rc;
+            if (k == started - 1 && started < n_pipes && (P.depth >= 2 || P.n == 0)) {
+                ++started;
+                if (next_pass < n_passes && (rc = start_pass(pipes[started - 1]))) return rc;
             }
             if (P.n == 0 || P.depth > cam->max_depth) {
                 P.state = Pipe::WAIT_ACC;
@@ -412,6 +432,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
                 return rc;
             }
         }
+        if (!progressed) std::this_thread::yield();
     }
     for (int k = 0; k < n_pipes; ++k) {
         if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 128, hipMemcpyDeviceToHost, pipes[k].s));
@@ -712,9 +733,9 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
 void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     if (hipSetDevice(sc->device) == hipSuccess) {
-        free_workspace(sc->ws[0]);
-        free_workspace(sc->ws[1]);
-        if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
+        for (auto& w : sc->ws) free_workspace(w);
+        for (auto& a : sc->aux_stream)
+            if (a) (void)hipStreamDestroy(a);
         if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
         for (auto& e : sc->ev_acc)
             if (e) (void)hipEventDestroy(e);
