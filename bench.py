@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra untimed one-pass-in-flight frame (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -197,9 +198,26 @@ def main():
         prim_s = sum(float(s["seconds_trace_primary"]) for s in stats)
         prim_seg = sum(int(s["primary_segments"]) for s in stats)
         bounce_rays_per_s = (seg0 - prim_seg) / max(trace_s - prim_s, 1e-12)
-        # visits per segment from one instrumented (untimed) low-spp render of the same frame
-        sst = step(collect=True, spp_override=min(spp, 4))
+        # Two untimed renders on THIS rank only (no collective: the other ranks are already at the final barrier):
+        # visits per segment from an instrumented low-spp render of the same frame, and the kernels' durations
+        # with one pass in flight (RT_HIP_PIPES=1), i.e. without other passes sharing the GPU
+        scratch = torch.zeros_like(rgb_sum)
+        img = rgb_mean.cpu().numpy()
+        sst = hip_render_sum(w._h, cam, min(spp, 4), 0, 1, 2024, scratch, local_rank, True)
         torch.cuda.synchronize()
+        a_bounce_s, a_bounce_seg, a_launches = 0.0, 0, 0
+        if not args.no_alone:
+            prev_pipes = os.environ.get("RT_HIP_PIPES")
+            os.environ["RT_HIP_PIPES"] = "1"
+            ast = hip_render_sum(w._h, cam, spp, 0, 1, 2024, scratch, local_rank, False)
+            torch.cuda.synchronize()
+            if prev_pipes is None:
+                del os.environ["RT_HIP_PIPES"]
+            else:
+                os.environ["RT_HIP_PIPES"] = prev_pipes
+            a_bounce_s = float(ast["seconds_trace"]) - float(ast["seconds_trace_primary"])
+            a_bounce_seg = int(ast["ray_segments"]) - int(ast["primary_segments"])
+            a_launches = int(ast["trace_launches"]) - int(ast["passes"])
         prim_bytes = info["tri_bytes"] if len(desc.triangles) >= len(desc.spheres) else info["sphere_bytes"]
         # the dominant kernel is the per-lane traversal of the bounce segments (k_trace<Box*>); camera rays go
         # through the packet kernel (k_trace_packet, f32 boxes of 64 B per node), reported beside it
@@ -220,7 +238,7 @@ def main():
         p_bytes_per_seg = 24 * (1 - a_on) + 76 * a_on + pv_n * 64 + pv_p * prim_bytes
         p_achieved = prim_seg * p_bytes_per_seg / prim_s / 1e9 if prim_s > 0 else 0.0
         traffic, p_traffic, traffic_src, valu = pmc_traffic(args.workload)
-        img = rgb_mean.cpu().numpy()
+        achieved_alone = a_bounce_seg * bytes_per_seg / a_bounce_s / 1e9 if a_bounce_s > 0 else 0.0
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,8 +255,13 @@ def main():
                          "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
                          "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
                          "rays_per_s": bounce_rays_per_s,
+                         # the same kernel with one pass in flight (one extra untimed frame after the timed region)
+                         "alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBS,
+                                   "avg_launch_ms": a_bounce_s / max(1, a_launches) * 1e3, "launches": a_launches,
+                                   "rays_per_s": a_bounce_seg / a_bounce_s if a_bounce_s > 0 else 0.0},
                          "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak; "
-                                 "two passes run on two streams, so event-timed kernel durations include time shared with the other pass" % (info["device_bytes"] / 2 ** 20)},
+                                 "several passes run on their own streams in the timed region, so its event-timed kernel durations include "
+                                 "time shared with the other passes; 'alone' is the same kernel with one pass in flight" % (info["device_bytes"] / 2 ** 20)},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic, "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading)",
                                 "avg_launch_ms": prim_s / max(1, n_launch - bounce_launches) * 1e3,

@@ -6,7 +6,7 @@ SW=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 one() {  # label, env assignment or empty
   local out
-  out=$(env $2 timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline "${@:3}") || return 1
+  out=$(env $2 timeout -k 10 300 python $ROOT/bench.py --no-cpu-baseline --no-alone "${@:3}") || return 1
   echo "$out" | tail -1 | python -c "import sys, json; j = json.loads(sys.stdin.read()); print('%-28s value=%8.1f ms/step=%7.2f' % ('$1', j['value'], j['ms_per_step']))"
 }
 for i in 1 2; do

@@ -39,7 +39,7 @@ def run(args):
             env = dict(os.environ)
             if n != "base":
                 env["RT_HIP_LIB"] = os.path.join(VDIR, n, "librt_hip.so")
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args, env=env,
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-alone"] + args, env=env,
                                capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 0 $*"
+ARGS="$ROOT/bench.py --no-cpu-baseline --no-alone --steps 1 --warmup 0 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
 pass() {
   name=$1; shift
