@@ -232,13 +232,17 @@ struct SurfaceHit {
 
 // Out of line on purpose: acos/atan2 in f64 are register-hungry and only image textures need uv;
 // inlining them costs the whole shade kernel two waves per SIMD of occupancy.
-__device__ __noinline__ void surface_uv(const SurfaceHit& h, double& u, double& v) {
-    if (h.is_sphere) {
-        sphere_uv(h.n, h.ss->rot, u, v);
+// (arguments and result by value: a reference parameter would put the hit record on the scratch stack of every wave)
+struct UV { double u, v; };
+__device__ __noinline__ UV surface_uv(bool is_sphere, D3 n, const double* rot, const TriShade* ts, const double* bu, const double* bv) {
+    UV r;
+    if (is_sphere) {
+        sphere_uv(n, rot, r.u, r.v);
     } else {                        // bbox-of-uvs mapping (src/hittable.rs:469-481)
-        u = h.ts->uv_left + h.ts->uv_width * *h.bu;
-        v = h.ts->uv_bot + h.ts->uv_height * *h.bv;
+        r.u = ts->uv_left + ts->uv_width * *bu;
+        r.v = ts->uv_bot + ts->uv_height * *bv;
     }
+    return r;
 }
 
 // Texture::value for the three kinds (src/texture.rs:25-29, :61-74, :99-118)
@@ -257,8 +261,8 @@ __device__ __forceinline__ D3 texture_value(const DScene& S, uint32_t ti, const 
             ti = (sum % 2 == 0) ? t->even : t->odd;
             continue;
         }
-        double u, v;
-        surface_uv(h, u, v);
+        const UV uv = surface_uv(h.is_sphere, h.n, h.is_sphere ? h.ss->rot : nullptr, h.ts, h.bu, h.bv);
+        const double u = uv.u, v = uv.v;
         double uc = clamp01(u), vc = clamp01(v);
         uint32_t w = t->width, ht = t->height;
         double fx = uc * (double)(w - 1), fy = vc * (double)(ht - 1);

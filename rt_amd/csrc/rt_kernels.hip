@@ -550,8 +550,14 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t
 // and stores them for k_shade.
 // FUSE (with GEN): the wave also shades its hits (depth 0) and appends the survivors to qo, so neither the
 // camera rays nor their hit records travel through HBM (k_shade at depth 0 is bound by exactly that traffic).
+// Six waves per SIMD (80 VGPRs, nine spilled) instead of the 85 registers / five waves the compiler picks on its own.
+// Frame rate with 5 / 6 / 7 / 8 waves: 1 M-triangle scene 6125 / 6227 / 6310 / 6150, cover scene 6450 / 6487 / 6340 / - Msamples/s.
+#ifndef RT_PK_WAVES
+#define RT_PK_WAVES 6
+#endif
+#define RT_PK_ATTR __attribute__((amdgpu_waves_per_eu(RT_PK_WAVES, RT_PK_WAVES)))
 template <bool STATS, bool GEN, bool FUSE>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueMap qm, double t_min,
+__global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueMap qm, double t_min,
                                                                double t_max, HitBuf hb, unsigned long long* counters,
                                                                RayQueue qo, ShardBases ob, uint32_t* out_counts, double* path_radiance) {
     __shared__ PacketEntry stack[BVH_MAX_DEPTH];
