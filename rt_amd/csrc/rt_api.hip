@@ -372,6 +372,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     };
 
     if ((rc = start_pass(pipes[0]))) return rc;
+    // The next pass starts when the one before it has finished its camera-ray launch: its camera rays (scalar-cache node
+    // fetches, coherent) then share the GPU with that pass's first bounce (vector gathers).  RT_HIP_STAGGER=<depth> for A/B:
+    // 0 / 1 / 2 / 3 -> 6747 / 6740 / 6590 / 6530 Msamples/s on the 1 M-triangle frame.
+    const char* sge = getenv("RT_HIP_STAGGER");
+    const uint32_t stagger_depth = sge ? (uint32_t)atoi(sge) : 1u;
     int started = 1;                 // pipes started so far: pipe k+1 starts once pipe k is past its bulk, so they stay out of phase
     while (done_passes < n_passes) {
         bool progressed = false;
@@ -421,7 +426,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             P.qm = queue_map_from_counts(P.ob, w.h_count, &P.n);
             P.cur ^= 1;
             P.depth++;
-            if (k == started - 1 && started < n_pipes && (P.depth >= 2 || P.n == 0)) {
+            if (k == started - 1 && started < n_pipes && (P.depth >= stagger_depth || P.n == 0)) {
                 ++started;
                 if (next_pass < n_passes && (rc = start_pass(pipes[started - 1]))) return rc;
             }
