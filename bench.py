@@ -116,17 +116,97 @@ def pmc_traffic(workload):
     return (pick("k_trace4<") or pick("k_trace<")), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start N fresh rank processes of this same
+    script, one per GPU, BEFORE anything in this process touches the GPU (a process that has initialised HIP must not
+    exec, and a parent holding a HIP context would only be in the way), relay rank 0's JSON line, and exit with the
+    worst exit status.  Under `python -m torch.distributed.run` WORLD_SIZE is set and this is skipped."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not STANDIN:
+        import torch                                   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+
+
+# RT_BENCH_STANDIN=1: launcher / partition / reduce self-test on CPU (gloo, a synthetic per-sample "renderer" defined
+# below).  It measures nothing and says so in its JSON line; tests/test_bench_launcher.py drives it at world size 2.
+STANDIN = os.environ.get("RT_BENCH_STANDIN") == "1"
+
+
+def standin_main(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from rt_amd.distributed import render_distributed
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_val, spp = 24, 5
+
+    def sample_image(s):            # a deterministic "radiance" of global sample index s
+        return torch.arange(n_val, dtype=torch.float64) * 0.25 + float(s * s % 7)
+
+    def render_sum(n_spp, offset, stride, seed, out_sum):
+        for k in range(n_spp):
+            out_sum += sample_image(offset + k * stride)
+        return None
+
+    out = torch.zeros(n_val, dtype=torch.float64)
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        mean, _ = render_distributed(render_sum, out, spp, seed=0)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        want = sum(sample_image(s) for s in range(spp * world)) / float(spp * world)
+        print(json.dumps({"metric": "launcher self-test (not a measurement)", "value": 0.0, "unit": "none", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "standin-selftest",
+                          "config": {"workload": "synthetic per-sample images over gloo", "partition": f"sample index mod {world}"},
+                          "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "standin_max_abs_err": float((mean - want).abs().max())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if STANDIN:
+        return standin_main(args, rank, world)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the product path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} (only {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     # RT_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (exercises the collective path on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
@@ -273,6 +353,7 @@ def main():
             "scene": {"bvh_nodes": info["n_nodes"], "bvh_depth": info["bvh_depth"], "device_mb": info["device_bytes"] / 2 ** 20,
                       "bvh_build_s": info["build_seconds"], "upload_s": info["upload_seconds"], "create_s": create_s},
             "image_mean": float(img.mean()),
+            "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, args.cpu_seconds)

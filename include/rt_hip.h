@@ -178,6 +178,21 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 int rt_trace_closest(const rt_scene* scene, const rt_ray* rays, size_t n,
                      double t_min, double t_max, rt_hit* out, rt_stats* stats /* may be NULL */);
 
+/* The same closest-hit query for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is rt_trace_closest with
+ *   - d_rays / d_hits in DEVICE memory (n entries each, owned by the caller),
+ *   - the ray queue and hit buffer of the batch in a fixed device array inside the library (21.3 MB on every GPU
+ *     the library runs on, until the process ends) instead of a workspace allocated on demand,
+ *   - at most RT_NOALLOC_MAX_RAYS rays per call (RT_ERR_LIMIT beyond that; split larger batches),
+ *   - the work only QUEUED on `stream` (a hipStream_t, NULL = default): it returns without synchronising, and
+ *     calls no hipMalloc / hipFree / hipHostMalloc or any other allocating routine.
+ * All calls on one GPU share that GPU's array: calls whose kernels can overlap on one GPU (two streams, two
+ * threads) race on it — order them on one stream or with events.  The scene must have been created on its
+ * device first (rt_scene_create also looks up the array's address on that device). */
+#define RT_NOALLOC_MAX_RAYS (1u << 18)
+int rt_trace_closest_noalloc(const rt_scene* scene, const rt_ray* d_rays, size_t n,
+                             double t_min, double t_max, rt_hit* d_hits, void* stream);
+
 /* Camera::get_ray(x, y, i) (src/camera.rs:231-254) followed by World::hit, for every pixel of the
  * camera and one global sample index; out has width*height entries, row-major.  With
  * jitter == 0 it is Camera::debug_ray (:256-260) at integer pixel coordinates. */

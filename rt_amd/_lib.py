@@ -36,6 +36,7 @@ def lib():
     L.rt_scene_destroy.restype = None
     L.rt_scene_get_info.argtypes = [vp, vp]
     L.rt_trace_closest.argtypes = [vp, vp, sz, dbl, dbl, vp, vp]
+    L.rt_trace_closest_noalloc.argtypes = [vp, vp, sz, dbl, dbl, vp, vp]
     L.rt_trace_primary.argtypes = [vp, vp, u32, i32, u64, vp, vp]
     L.rt_render.argtypes = [vp, vp, vp, vp, vp]
     L.rt_render_accumulate_device.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -51,7 +52,7 @@ def lib():
 # every symbol include/rt_hip.h declares
 EXPORTS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
-    "rt_scene_get_info", "rt_trace_closest", "rt_trace_primary", "rt_render",
+    "rt_scene_get_info", "rt_trace_closest", "rt_trace_closest_noalloc", "rt_trace_primary", "rt_render",
     "rt_render_accumulate_device", "rt_resolve_device", "rt_encode_gamma8",
 ]
 

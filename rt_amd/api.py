@@ -210,6 +210,18 @@ class SceneDesc:
         self.textures = np.zeros(0, _abi.texture_dt) if textures is None else np.ascontiguousarray(textures, _abi.texture_dt)
         self.texel_pool = np.zeros(0, np.uint8) if texel_pool is None else np.ascontiguousarray(texel_pool, np.uint8)
         self.sky = sky_synth_v1() if sky is None else sky
+        # prim id (the [spheres..., triangles...] order of the ABI) -> position in the caller's shapes list, and
+        # the index inside that entry when it is a TriangleSoup; None when the arrays were given directly
+        self.prim_shape = None
+        self.prim_sub = None
+
+    def shape_of(self, prim):
+        """(index in the shapes list handed to from_shapes, index inside that entry) of primitive id(s) `prim`
+        — the reference's `Vec<Shape>` position for mixed sphere / triangle lists."""
+        if self.prim_shape is None:
+            raise ValueError("this SceneDesc was not built by from_shapes")
+        p = np.asarray(prim, dtype=np.int64)
+        return self.prim_shape[p], self.prim_sub[p]
 
     @property
     def n_prims(self):
@@ -280,6 +292,16 @@ class SceneDesc:
         tri = [t for t in shapes if isinstance(t, (Triangle, TriangleSoup))]
         if len(sph) + len(tri) != len(shapes):
             raise TypeError("shapes must be Sphere, Triangle or TriangleSoup")
+        # the ABI orders primitives [spheres..., triangles...]; remember where each one sat in `shapes`
+        sph_pos = [i for i, s in enumerate(shapes) if isinstance(s, Sphere)]
+        tri_pos, tri_sub = [], []
+        for i, t in enumerate(shapes):
+            if isinstance(t, Triangle):
+                tri_pos.append(np.array([i], dtype=np.int64))
+                tri_sub.append(np.zeros(1, dtype=np.int64))
+            elif isinstance(t, TriangleSoup):
+                tri_pos.append(np.full(len(t), i, dtype=np.int64))
+                tri_sub.append(np.arange(len(t), dtype=np.int64))
         S = np.zeros(len(sph), _abi.sphere_dt)
         for i, s in enumerate(sph):
             S[i]["center"], S[i]["radius"], S[i]["face"], S[i]["material"] = s.center, s.radius, s.front_direction, mat_id(s.material)
@@ -309,7 +331,10 @@ class SceneDesc:
         T = np.concatenate(parts) if parts else np.zeros(0, _abi.triangle_dt)
         M = np.array(mats, dtype=_abi.material_dt) if mats else np.zeros(0, _abi.material_dt)
         X = np.array(texs, dtype=_abi.texture_dt) if texs else np.zeros(0, _abi.texture_dt)
-        return SceneDesc(S, T, M, X, np.frombuffer(bytes(pool), dtype=np.uint8).copy(), sky)
+        desc = SceneDesc(S, T, M, X, np.frombuffer(bytes(pool), dtype=np.uint8).copy(), sky)
+        desc.prim_shape = np.concatenate([np.array(sph_pos, dtype=np.int64)] + tri_pos)
+        desc.prim_sub = np.concatenate([np.zeros(len(sph_pos), dtype=np.int64)] + tri_sub)
+        return desc
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,7 +369,8 @@ class World:
             r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1, 6).view(_abi.ray_dt).reshape(-1)
         r = np.ascontiguousarray(r)
         out = np.zeros(len(r), _abi.hit_dt)
-        st = _abi.one(_abi.stats_dt)
+        # (a stats pointer selects the instrumented traversal kernels: only when asked for)
+        st = _abi.one(_abi.stats_dt) if with_stats else None
         check(lib().rt_trace_closest(self._h, _abi.ptr(r), len(r), t_min, t_max, _abi.ptr(out), _abi.ptr(st)))
         return (out, st[0]) if with_stats else out
 

@@ -55,6 +55,17 @@ int fail(int code, const char* fmt, ...) {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_device_mu[MAX_DEVICES];
 
+// Every entry point that needs a device makes it current through a DeviceGuard, which puts the caller's
+// current device back on return: a single-process multi-GPU host (or torch with another current device)
+// keeps its own selection across calls into the library.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) { (void)hipSetDevice(prev); } }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int select_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -91,6 +102,31 @@ struct DevAllocs {
 };
 
 constexpr int MAX_PIPES = 8;
+
+// ---- scratch of rt_trace_closest_noalloc (include/rt_hip.h) -------------------------------------
+// The ray queue (o, d: 6 doubles + path id) and the hit buffer (t, bu, bv + primitive id) of one bounded batch live
+// in a file-scope device array instead of a hipMalloc'ed workspace: 80 B per queue slot, RT_NOALLOC_MAX_RAYS rays +
+// QUEUE_SLACK slots of shard padding = 21.3 MB, held by every GPU the library runs on until the process ends.
+// `g_noalloc_scratch` is only a host-side stand-in for the symbol: host code uses the per-device ADDRESS obtained
+// once per device with hipGetSymbolAddress (noalloc_scratch_for), never the array's name.
+constexpr size_t NOALLOC_SLOTS = (size_t)RT_NOALLOC_MAX_RAYS + QUEUE_SLACK;
+constexpr size_t NOALLOC_DOUBLES = 9 * NOALLOC_SLOTS;      // o[3], d[3], t, bu, bv
+constexpr size_t NOALLOC_U32S = 2 * NOALLOC_SLOTS;         // path id, primitive id
+constexpr size_t NOALLOC_BYTES = NOALLOC_DOUBLES * sizeof(double) + NOALLOC_U32S * sizeof(uint32_t);
+static __device__ __align__(256) unsigned char g_noalloc_scratch[NOALLOC_BYTES];
+unsigned char* g_noalloc_ptr[MAX_DEVICES] = {};            // device address of the array on each device (under g_device_mu)
+
+// call with `device` current and g_device_mu[device] held
+int noalloc_scratch_for(int device, unsigned char** out) {
+    if (!g_noalloc_ptr[device]) {
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned NULL for the no-alloc scratch");
+        g_noalloc_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_noalloc_ptr[device];
+    return RT_OK;
+}
 
 struct Workspace {
     size_t capacity = 0;          // paths
@@ -507,8 +543,9 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         if (t.kind == RT_TEX_IMAGE) {
             if (t.texel_format > RT_TEXEL_RGBA16) return fail(RT_ERR_INVALID, "texture %zu: bad texel format", i);
             const size_t bpt = t.texel_format == RT_TEXEL_RGBA16 ? 8 : 4;
-            if (!t.width || !t.height || (t.texel_offset % bpt) != 0 ||
-                t.texel_offset + (size_t)t.width * t.height * bpt > texel_pool_bytes)
+            // (no product or sum that could wrap: width * height fits 64 bits, the rest is divided out)
+            if (!t.width || !t.height || (t.texel_offset % bpt) != 0 || t.texel_offset > (uint64_t)texel_pool_bytes ||
+                (uint64_t)t.width * t.height > ((uint64_t)texel_pool_bytes - t.texel_offset) / bpt)
                 return fail(RT_ERR_INVALID, "texture %zu: image outside the texel pool", i);
         }
     }
@@ -528,8 +565,14 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         if (!finite3(triangles[i].a) || !finite3(triangles[i].b) || !finite3(triangles[i].c))
             return fail(RT_ERR_INVALID, "triangle %zu: non-finite vertex", i);
     }
+    DeviceGuard dg;
     int rc = select_device(device);
     if (rc) return rc;
+    {   // set-up of the allocation-free entry point: this device's address of the scratch array, once per device
+        std::lock_guard<std::mutex> dl(g_device_mu[device]);
+        unsigned char* scratch = nullptr;
+        if ((rc = noalloc_scratch_for(device, &scratch))) return rc;
+    }
 
     rt_scene* sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OOM, "out of host memory");
@@ -737,6 +780,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
 
 void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
+    DeviceGuard dg;
     if (hipSetDevice(sc->device) == hipSuccess) {
         for (auto& w : sc->ws) free_workspace(w);
         for (auto& a : sc->aux_stream)
@@ -765,6 +809,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     if (!n) return RT_OK;
     std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
     std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
     int rc = select_device(sc->device);
     if (rc) return rc;
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
@@ -809,6 +854,45 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     return RT_OK;
 }
 
+int rt_trace_closest_noalloc(const rt_scene* csc, const rt_ray* d_rays, size_t n, double t_min, double t_max,
+                             rt_hit* d_hits, void* stream_) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "d_rays/d_hits is NULL");
+    if (n > (size_t)RT_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_LIMIT, "rt_trace_closest_noalloc: %zu rays exceed the scratch array's limit of %u per call", n,
+                    (unsigned)RT_NOALLOC_MAX_RAYS);
+    if (!n) return RT_OK;
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    DeviceGuard dg;
+    int rc = select_device(sc->device);
+    if (rc) return rc;
+    unsigned char* base = nullptr;                      // the device address kept at set-up (rt_scene_create)
+    if ((rc = noalloc_scratch_for(sc->device, &base))) return rc;
+    // carve the array: every kernel below gets these pointers as arguments, like the workspace of rt_trace_closest
+    double* dp = (double*)base;
+    uint32_t* up = (uint32_t*)(base + NOALLOC_DOUBLES * sizeof(double));
+    RayQueue q{};
+    HitBuf hb{};
+    for (int c = 0; c < 3; ++c) q.o[c] = dp + (size_t)c * NOALLOC_SLOTS;
+    for (int c = 0; c < 3; ++c) q.d[c] = dp + (size_t)(3 + c) * NOALLOC_SLOTS;
+    for (int c = 0; c < 3; ++c) q.thr[c] = nullptr;     // the traversal never touches the throughput
+    hb.t = dp + 6 * NOALLOC_SLOTS;
+    hb.bu = dp + 7 * NOALLOC_SLOTS;
+    hb.bv = dp + 8 * NOALLOC_SLOTS;
+    q.pid = up;
+    hb.prim = up + NOALLOC_SLOTS;
+    hipStream_t stream = (hipStream_t)stream_;
+    // Nothing has to start at zero: k_prepare_rays writes every queue slot the traversal reads, the traversal writes t and
+    // prim of every one of them (bu / bv are not read by k_pack_hits), and no counter is involved (stats are off).
+    const QueueMap qm = queue_map_single((uint32_t)n);
+    launch_prepare_rays(d_rays, qm, q, stream);
+    launch_trace(sc->d, q, qm, t_min, t_max, hb, false, nullptr, stream);
+    launch_pack_hits(hb, qm, d_hits, stream);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_index, int jitter, uint64_t seed,
                      rt_hit* out, rt_ray* rays_out) {
     rt_scene* sc = const_cast<rt_scene*>(csc);
@@ -820,6 +904,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     if (npix > PRIMARY_MAX_PIXELS) return fail(RT_ERR_LIMIT, "rt_trace_primary: more than 2^25 pixels");
     std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
     std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
     if ((rc = ensure_workspace(sc, npix))) return rc;
     Workspace& w = sc->ws[0];
@@ -841,7 +926,11 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     hipStream_t stream = nullptr;
     const QueueMap qm = queue_map_single((uint32_t)npix);
     launch_raygen(pp, qm, w.q[0], stream);
-    launch_trace(sc->d, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
+    // RT_HIP_PRIMARY_PACKET=1 (tests): the coherent-wave kernel that rt_render uses for camera rays, on the same rays
+    if (getenv("RT_HIP_PRIMARY_PACKET") && packet_supported(sc->d))
+        launch_trace_packet(sc->d, nullptr, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream, nullptr);
+    else
+        launch_trace(sc->d, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
     launch_pack_hits(w.hb, qm, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {
@@ -863,6 +952,7 @@ int rt_render_accumulate_device(const rt_scene* csc, const rt_camera* cam, const
         return fail(RT_ERR_INVALID, "opts.device (%d) differs from the scene's device (%d)", opts->device, sc->device);
     std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
     std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
     return render_into(sc, cam, opts, d_rgb_sum, (hipStream_t)stream, stats);
 }
@@ -871,6 +961,7 @@ int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_valu
                       void* stream) {
     if (!d_rgb_sum || !d_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
     if (!total_spp) return fail(RT_ERR_INVALID, "total_spp must be >= 1");
+    DeviceGuard dg;
     int rc = select_device(device);
     if (rc) return rc;
     launch_resolve(d_rgb_sum, d_rgb_mean, n_values, (double)total_spp, (hipStream_t)stream);
@@ -887,6 +978,7 @@ int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, do
         return fail(RT_ERR_INVALID, "opts.device (%d) differs from the scene's device (%d)", opts->device, sc->device);
     std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
     std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
     const size_t nval = (size_t)cam->width * cam->height * 3;
     DevAllocs tmp;

@@ -134,7 +134,7 @@ class World {
 public:
     World(const World&) = delete;
     World& operator=(const World&) = delete;
-    World(World&& o) noexcept : h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+    World(World&& o) noexcept : h_(o.h_), device_(o.device_), prim_shape_(std::move(o.prim_shape_)) { o.h_ = nullptr; }
     ~World() { rt_scene_destroy(h_); }
 
     // Flattens `shapes` ([spheres..., triangles...] keeps each kind's order) and uploads to `device`.
@@ -165,7 +165,10 @@ public:
             M.push_back(r);
             return mid[m.get()] = uint32_t(M.size() - 1);
         };
-        for (const Shape& s : shapes) {
+        std::vector<uint32_t> sph_pos, tri_pos;        // where each primitive sat in `shapes`
+        for (size_t si = 0; si < shapes.size(); ++si) {
+            const Shape& s = shapes[si];
+            (std::holds_alternative<Sphere>(s) ? sph_pos : tri_pos).push_back(uint32_t(si));
             if (const Sphere* sp = std::get_if<Sphere>(&s)) {
                 rt_sphere r; std::memset(&r, 0, sizeof(r));
                 store(sp->center, r.center); r.radius = sp->radius; store(sp->front_direction, r.face); r.material = mat(sp->material);
@@ -181,8 +184,14 @@ public:
         rt_scene* h = nullptr;
         check(rt_scene_create(S.data(), S.size(), T.data(), T.size(), M.data(), M.size(), X.data(), X.size(),
                               pool.data(), pool.size(), &sky, device, &h));
-        return World(h, device);
+        World w(h, device);
+        w.prim_shape_ = std::move(sph_pos);
+        w.prim_shape_.insert(w.prim_shape_.end(), tri_pos.begin(), tri_pos.end());
+        return w;
     }
+    // Position in the `shapes` vector handed to build() of primitive id `prim` (the ABI orders primitives
+    // [spheres..., triangles...]; this maps a hit back to the reference's Vec<Shape> index for mixed lists).
+    uint32_t shape_of(uint32_t prim) const { return prim_shape_.at(prim); }
 
     std::vector<rt_hit> hit(const std::vector<rt_ray>& rays, double t_min = 0.001, double t_max = 1.7976931348623157e308) const {
         std::vector<rt_hit> out(rays.size());
@@ -196,6 +205,7 @@ private:
     World(rt_scene* h, int device) : h_(h), device_(device) {}
     rt_scene* h_;
     int device_;
+    std::vector<uint32_t> prim_shape_;
 };
 
 // ---- Camera (src/camera.rs) -----------------------------------------------------------------------
