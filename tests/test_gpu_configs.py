@@ -80,13 +80,13 @@ def test_textured_triangle_uv_reaches_the_texel(oracle):
     mat = Lambertian(ImageTexture(img))
     a, b, c, d = (-2.0, 0.0, -1.0), (2.0, 0.0, -1.0), (2.0, 0.0, 1.0), (-2.0, 0.0, 1.0)
     # wound so the stored normal faces -y (towards the camera); uvs span sub-rectangles of the image
-    shapes = [Triangle.new_with_uv(a, c, b, (0.1, 0.9), (0.8, 0.2), (0.8, 0.9), mat),
-              Triangle.new_with_uv(a, d, c, (0.0, 0.3), (0.2, 0.0), (0.9, 0.1), mat)]
+    shapes = [Triangle.new_with_uv(a, b, c, (0.1, 0.9), (0.8, 0.9), (0.8, 0.2), mat),
+              Triangle.new_with_uv(a, c, d, (0.0, 0.3), (0.9, 0.1), (0.2, 0.0), mat)]
     desc = SceneDesc.from_shapes(shapes)
     world, orc = World.build(desc), oracle.OracleScene(desc)
     cam = Camera.new((0.0, -6.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 6.0, 0.0, 96, 48, 2, 1, 30.0)
     hits = cam.trace_primary(world, 0, jitter=True)
-    assert (hits["prim"] != _abi.RT_MISS).mean() > 0.5
+    assert (hits["prim"] != _abi.RT_MISS).mean() > 0.3
     gpu, st = cam.render_image(world, spp=2, seed=5, with_stats=True)
     ref, rst = orc.render(cam, 2, seed=5, mode=oracle.BRUTE, with_stats=True)
     assert int(st["ray_segments"]) == int(rst["ray_segments"])
