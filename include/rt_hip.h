@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 #define RT_MISS 0xFFFFFFFFu
 /* Camera::new builds a Halton table of 1024*1024 points (src/camera.rs:208-210); a sample index
  * beyond it would index out of bounds in the reference, so it is an API limit here. */
@@ -128,19 +128,28 @@ typedef struct rt_opts {
 
 typedef struct rt_stats {
     uint64_t samples;        /* camera paths traced                                     */
-    uint64_t ray_segments;   /* closest-hit queries (primary + bounce)                  */
+    uint64_t ray_segments;   /* closest-hit queries: primary + bounce + tail            */
     uint64_t nodes_visited;  /* only when collect_stats                                 */
     uint64_t prims_tested;   /* only when collect_stats                                 */
     uint32_t passes, launches;
-    double seconds_trace;    /* device time in the trace kernel (HIP events)            */
-    double seconds_shade;    /* device time in raygen + shade + accumulate              */
-    double seconds_total;    /* device time first launch -> last launch                 */
-    uint64_t trace_launches; /* number of trace-kernel launches timed in seconds_trace  */
+    double seconds_trace;    /* device time (HIP events on the kernels' streams) in the camera-ray kernels and the
+                                stand-alone bounce traversal launches                    */
+    double seconds_shade;    /* device time in the stand-alone shade + accumulate launches */
+    double seconds_total;    /* host time first launch -> everything finished           */
+    uint64_t trace_launches; /* number of launches timed in seconds_trace               */
     uint64_t primary_segments;     /* camera rays (depth 0) among ray_segments                 */
-    double seconds_trace_primary;  /* part of seconds_trace spent on depth-0 launches; the
-                                      rest is the incoherent-bounce part                      */
+    double seconds_trace_primary;  /* part of seconds_trace spent on the depth-0 launches      */
     uint64_t nodes_visited_primary; /* parts of nodes_visited / prims_tested counted by the    */
     uint64_t prims_tested_primary;  /* depth-0 (camera ray) launches; only when collect_stats  */
+    /* ---- ABI v2 ---- */
+    uint64_t bounce_segments;      /* segments of the stand-alone bounce traversal launches (k_walk: the dominant kernel) */
+    double seconds_trace_bounce;   /* their event-timed duration (part of seconds_trace)       */
+    uint64_t bounce_launches;
+    uint64_t tail_segments;        /* segments traced AND shaded inside the persistent tail kernel (depth >= 2) */
+    double seconds_tail;           /* its event-timed duration                                 */
+    uint64_t nodes_visited_bounce, prims_tested_bounce;   /* collect_stats: the stand-alone bounce launches alone */
+    uint64_t wave_node_fetches_primary;  /* collect_stats: node / primitive records the coherent camera-ray kernel  */
+    uint64_t wave_prim_fetches_primary;  /* fetched once per WAVE (its memory traffic; the *_primary counts are per lane) */
 } rt_stats;
 
 typedef struct rt_ray { double o[3], d[3]; } rt_ray;   /* d need not be normalised: Ray::new does */

@@ -38,7 +38,11 @@ stats_dt = np.dtype([("samples", "<u8"), ("ray_segments", "<u8"), ("nodes_visite
                      ("prims_tested", "<u8"), ("passes", "<u4"), ("launches", "<u4"),
                      ("seconds_trace", "<f8"), ("seconds_shade", "<f8"), ("seconds_total", "<f8"),
                      ("trace_launches", "<u8"), ("primary_segments", "<u8"), ("seconds_trace_primary", "<f8"),
-                     ("nodes_visited_primary", "<u8"), ("prims_tested_primary", "<u8")])
+                     ("nodes_visited_primary", "<u8"), ("prims_tested_primary", "<u8"),
+                     ("bounce_segments", "<u8"), ("seconds_trace_bounce", "<f8"), ("bounce_launches", "<u8"),
+                     ("tail_segments", "<u8"), ("seconds_tail", "<f8"),
+                     ("nodes_visited_bounce", "<u8"), ("prims_tested_bounce", "<u8"),
+                     ("wave_node_fetches_primary", "<u8"), ("wave_prim_fetches_primary", "<u8")])
 ray_dt = np.dtype([("o", "<f8", 3), ("d", "<f8", 3)])
 hit_dt = np.dtype([("t", "<f8"), ("prim", "<u4"), ("_pad", "<u4")])
 scene_info_dt = np.dtype([("n_prims", "<u8"), ("n_nodes", "<u8"), ("device_bytes", "<u8"),
@@ -53,7 +57,7 @@ isect_dt = np.dtype([("point", "<f8", 3), ("normal", "<f8", 3), ("uv", "<f8", 2)
 EXPECTED_SIZES = {
     "rt_sphere": (sphere_dt, 64), "rt_triangle": (triangle_dt, 152), "rt_material": (material_dt, 32),
     "rt_texture": (texture_dt, 64), "rt_sky": (sky_dt, 144), "rt_camera": (camera_dt, 184),
-    "rt_opts": (opts_dt, 40), "rt_stats": (stats_dt, 104), "rt_ray": (ray_dt, 48), "rt_hit": (hit_dt, 16),
+    "rt_opts": (opts_dt, 40), "rt_stats": (stats_dt, 176), "rt_ray": (ray_dt, 48), "rt_hit": (hit_dt, 16),
     "rt_scene_info": (scene_info_dt, 72),
 }
 for _name, (_dt, _size) in EXPECTED_SIZES.items():

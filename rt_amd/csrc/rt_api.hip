@@ -22,7 +22,7 @@
 
 static_assert(sizeof(rt_sphere) == 64 && sizeof(rt_triangle) == 152 && sizeof(rt_material) == 32 &&
                   sizeof(rt_texture) == 64 && sizeof(rt_sky) == 144 && sizeof(rt_camera) == 184 &&
-                  sizeof(rt_opts) == 40 && sizeof(rt_stats) == 104 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
+                  sizeof(rt_opts) == 40 && sizeof(rt_stats) == 176 && sizeof(rt_ray) == 48 && sizeof(rt_hit) == 16 &&
                   sizeof(rt_scene_info) == 72,
               "ABI struct sizes (mirrored in rt_amd/_abi.py)");
 
@@ -135,11 +135,10 @@ struct Workspace {
     RayQueue q[2];
     HitBuf hb;
     double* path_radiance = nullptr;
-    uint32_t* counters = nullptr;             // 2 sets of NSHARD counters, 128 B apart
-    unsigned long long* stat_counters = nullptr;   // [2], own 256-B block
-    uint32_t* h_count = nullptr;              // pinned
-    unsigned long long* h_stat = nullptr;     // pinned [2]
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t* counters = nullptr;                  // 2 sets of NSHARD queue counters, 128 B apart (device only: no host copy exists)
+    unsigned long long* stat_counters = nullptr;   // STAT_GROUPS groups of STAT_GROUP u64
+    unsigned long long* h_stat = nullptr;          // pinned copy of them
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the pass in flight
 };
 
 }  // namespace
@@ -153,25 +152,36 @@ struct rt_scene {
     bool device_built = false;       // BVH from bvh_gpu.hip
     Workspace ws[MAX_PIPES];         // one per in-flight pass (DEFAULT_PIPES passes are pipelined by default)
     hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {};
+    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {};
+    // progressive preview state (rt_render_pass): per-pass sums, the running float frame and the 8-bit linear frame
+    double* pv_sum = nullptr;
+    double* pv_mean = nullptr;
+    uint8_t* pv_rgba8 = nullptr;
+    size_t pv_pixels = 0;
+    uint64_t pv_total = 0;
 };
 
 namespace {
 
 void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
-    if (w.h_count) (void)hipHostFree(w.h_count);
     if (w.h_stat) (void)hipHostFree(w.h_stat);
     for (auto& e : w.ev)
         if (e) (void)hipEventDestroy(e);
     w = Workspace();
 }
 
+size_t workspace_bytes(size_t paths) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t slots = paths + QUEUE_SLACK;     // sharded queues pad every shard to a multiple of 64
+    const size_t dsz = up(slots * sizeof(double)), usz = up(slots * sizeof(uint32_t));
+    return 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 2 * COUNTER_BYTES + STAT_BYTES;
+}
+
 int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
     Workspace& w = sc->ws[which];
-    if (!w.h_count) {
-        HIPCHK(hipHostMalloc((void**)&w.h_count, COUNTER_BYTES, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void**)&w.h_stat, 256, hipHostMallocDefault));
+    if (!w.h_stat) {
+        HIPCHK(hipHostMalloc((void**)&w.h_stat, STAT_BYTES, hipHostMallocDefault));
         for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
     }
     if (paths <= w.capacity) return RT_OK;
@@ -179,11 +189,12 @@ int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
         (void)hipFree(w.base);
         w.base = nullptr;
         w.capacity = 0;
+        w.bytes = 0;
     }
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t slots = paths + QUEUE_SLACK;     // sharded queues pad every shard to a multiple of 64
+    const size_t slots = paths + QUEUE_SLACK;
     const size_t dsz = up(slots * sizeof(double)), usz = up(slots * sizeof(uint32_t));
-    size_t total = 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 2 * COUNTER_BYTES + 256;
+    const size_t total = workspace_bytes(paths);
     char* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total);
     if (e != hipSuccess) {
@@ -205,7 +216,7 @@ int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
     w.hb.prim = (uint32_t*)take(usz);
     w.path_radiance = (double*)take(up(3 * paths * sizeof(double)));
     w.counters = (uint32_t*)take(2 * COUNTER_BYTES);
-    w.stat_counters = (unsigned long long*)take(256);
+    w.stat_counters = (unsigned long long*)take(STAT_BYTES);
     w.capacity = paths;
     return RT_OK;
 }
@@ -260,14 +271,28 @@ int check_camera(const rt_camera* cam) {
 }
 
 // 2^26 paths = 32 samples per pixel and pass at 1080p: 204 B of path state each, four workspaces (four passes in
-// flight) = 55 GB of the 288 GB.  Measured on the 1 M-triangle frame (passes in flight x paths per pass, Msamples/s):
-// 2 x 2^27 5870, 3 x 2^27 6030, 4 x 2^27 6040, 3 x 2^26 6030, 4 x 2^26 6125, 6 x 2^26 6150, 4 x 2^25 6080, 8 x 2^25 6070:
-// large launches amortise the tails and host round trips, several passes in flight fill what one pass leaves idle.
+// flight) = 55 GB of the 288 GB.  Large launches amortise the tails, several passes in flight fill what one pass leaves idle.
 constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 26;
 constexpr int DEFAULT_PIPES = 4;
 constexpr size_t PRIMARY_MAX_PIXELS = size_t(1) << 25;
 
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
+//
+// A pass = per_pass samples of every pixel.  Its kernels are queued on one stream WITHOUT any host round trip:
+//   depth 0      k_trace_packet<GEN, FUSE>   camera rays: generate, trace (coherent waves), shade, compact -> queue + counts A
+//   depth 1      k_walk                      first bounce: per-lane BVH4 traversal of that queue (the dominant kernel)
+//                k_shade                     shade + Russian roulette, compact -> queue + counts B
+//   depth >= 2   k_walk<SHADE>               persistent: every remaining bounce of every surviving path inside one launch
+//   k_accumulate                             per-pixel sums in sample order (passes ordered by events), clears the counts
+// The entry counts of the queues never leave the device (QueueGeom); every consumer reads them there.  Up to four passes are
+// in flight on four streams; the host only waits when it reuses a pipe (to read its event timings) and at the end.
+// RT_HIP_TAIL_DEPTH=<d> (tests, A/B): depth from which the persistent kernel takes over (default 2; 1 = straight after the
+// camera rays; larger = more stand-alone k_walk + k_shade pairs first).  The image does not depend on it.
 int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
                 rt_stats* stats) {
     const uint32_t stride = opts->sample_stride ? opts->sample_stride : 1;
@@ -279,24 +304,54 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         return fail(RT_ERR_LIMIT, "sample index %llu exceeds the Halton table limit %u (src/camera.rs:208-210)",
                     (unsigned long long)last, RT_MAX_SAMPLE_INDEX);
     const size_t npix = (size_t)cam->width * cam->height;
-    const char* pfe = getenv("RT_HIP_PATHS_IN_FLIGHT");          // experiments: log2 of the default cap
-    const size_t dflt = pfe && atoi(pfe) >= 10 && atoi(pfe) <= 30 ? size_t(1) << atoi(pfe) : DEFAULT_PATHS_IN_FLIGHT;
+    const int pfe = env_int("RT_HIP_PATHS_IN_FLIGHT", 0);          // experiments: log2 of the default cap
+    const size_t dflt = pfe >= 10 && pfe <= 30 ? size_t(1) << pfe : DEFAULT_PATHS_IN_FLIGHT;
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
-    const uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
+    uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
-    const uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
-    // Several passes are kept in flight, one stream each: the tail of a pass (a dozen launches over a few
-    // thousand surviving paths, each as long as its slowest ray) and the per-bounce host round trip
-    // hide behind the other passes' bulk work.  RT_HIP_PIPES=<n> sets the number (1 disables the overlap).
-    const char* pe = getenv("RT_HIP_PIPES");
-    const int n_pipes = (int)std::min<uint32_t>(n_passes, pe && atoi(pe) >= 1 ? (uint32_t)std::min(atoi(pe), MAX_PIPES) : (uint32_t)DEFAULT_PIPES);
-    const bool poll_blocking = getenv("RT_HIP_BLOCKING_POLL") != nullptr;      // A/B: the round-robin blocking wait
+    // Several passes are kept in flight, one stream each: the tail of a pass (few paths, long dependent chains) hides
+    // behind the other passes' bulk work.  RT_HIP_PIPES=<n> sets the number (1 disables the overlap).
+    const int pe = env_int("RT_HIP_PIPES", 0);
+    const uint32_t want_pipes = pe >= 1 ? (uint32_t)std::min(pe, MAX_PIPES) : (uint32_t)DEFAULT_PIPES;
+    uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
+    int n_pipes = (int)std::min<uint32_t>(n_passes, want_pipes);
     int rc;
-    for (int k = 0; k < n_pipes; ++k)
-        if ((rc = ensure_workspace(sc, npix * per_pass, k))) return rc;
-    if (n_pipes > 1 && !sc->ev_fork) {
+    // Workspaces: n_pipes x (per_pass x pixels) paths.  When the device cannot hold them (a shared or smaller-HBM GPU) the
+    // render goes on with fewer passes in flight, then with smaller passes, instead of failing.
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // what the workspaces would take beyond what this scene already holds (an outgrown one is freed first)
+            auto extra = [&](int pipes_, uint32_t per_) {
+                size_t add = 0;
+                for (int k = 0; k < pipes_; ++k)
+                    if (sc->ws[k].capacity < npix * per_) add += workspace_bytes(npix * per_) - std::min(workspace_bytes(npix * per_), sc->ws[k].bytes);
+                return add;
+            };
+            while (extra(n_pipes, per_pass) > free_b - free_b / 32 && !(per_pass == 1 && n_pipes == 1)) {
+                if (n_pipes > 1) --n_pipes; else per_pass = (per_pass + 1) / 2;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+        for (;;) {
+            int got = 0;
+            rc = RT_OK;
+            for (int k = 0; k < n_pipes && !rc; ++k)
+                if (!(rc = ensure_workspace(sc, npix * per_pass, k))) ++got;
+            if (!rc) break;
+            if (rc != RT_ERR_OOM) return rc;
+            if (got >= 1) { n_pipes = got; break; }
+            if (per_pass == 1) return rc;
+            per_pass = (per_pass + 1) / 2;
+        }
+        n_passes = (opts->spp + per_pass - 1) / per_pass;
+        n_pipes = (int)std::min<uint32_t>(n_passes, (uint32_t)n_pipes);
+    }
+    if (!sc->ev_fork) {
         HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : sc->ev_cam) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (int k = 1; k < n_pipes; ++k)
         if (!sc->aux_stream[k]) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
@@ -313,24 +368,21 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     pp0.group = 1;
     // samples of a pixel that share a wave of camera rays: as many as the pass and the frame allow
     // (RT_HIP_GROUP=1|4|16|64 caps it; 1 = one sample of an 8x8 tile per wave)
-    const char* ge = getenv("RT_HIP_GROUP");
-    const uint32_t group_cap = ge && atoi(ge) > 0 ? (uint32_t)atoi(ge) : 16u;
+    const int ge = env_int("RT_HIP_GROUP", 0);
+    const uint32_t group_cap = ge > 0 ? (uint32_t)ge : 16u;
 
     rt_stats st;
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
     const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
     const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");      // depth-0 shading inside the camera-ray kernel
+    const uint32_t tail_depth = (uint32_t)std::max(1, env_int("RT_HIP_TAIL_DEPTH", 2));
+    const bool stagger = env_int("RT_HIP_STAGGER", 1) != 0;               // a pass starts when the one before it has traced its camera rays
 
     struct Pipe {
         Workspace* w = nullptr;
         hipStream_t s = nullptr;
-        PassParams pp;
-        QueueMap qm;
-        ShardBases ob;
-        uint32_t pass = 0, nl = 0, n = 0, depth = 0;
-        int cur = 0;
-        enum { IDLE, RUNNING, WAIT_ACC } state = IDLE;
+        bool in_flight = false;
     } pipes[MAX_PIPES];
     for (int k = 0; k < n_pipes; ++k) {
         pipes[k].w = &sc->ws[k];
@@ -340,165 +392,152 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
         for (int k = 1; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
     }
-    for (int k = 0; k < n_pipes; ++k)
-        if (want_stats) HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, 256, pipes[k].s));
-
-    uint32_t next_pass = 0, next_acc = 0, done_passes = 0;
-    int last_acc_pipe = -1;
+    for (int k = 0; k < n_pipes; ++k) {
+        // queue counters start at zero (every pass leaves them cleared again: k_accumulate), statistics too
+        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES, pipes[k].s));
+        HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
+    }
     const double t0 = now_s();
 
-    // one bounce of pipe P: zero counters, trace, shade (+compaction), read back the shard counts
-    auto submit = [&](Pipe& P) -> int {
+    // event timings of the pass a pipe has finished (phases: camera rays | first-bounce traversal | shading | tail | sums)
+    auto collect = [&](Pipe& P) -> int {
+        if (!P.in_flight) return RT_OK;
         Workspace& w = *P.w;
-        uint32_t* d_count = w.counters + (COUNTER_BYTES / 4) * (P.depth & 1u);
-        P.ob = shard_bases_for(P.qm);
-        HIPCHK(hipMemsetAsync(d_count, 0, COUNTER_BYTES, P.s));
-        HIPCHK(hipEventRecord(w.ev[2], P.s));
-        bool shaded = false;
-        if (P.depth == 0 && use_packet) {   // camera rays: coherent waves; generated, traced and (fused) shaded in one kernel
-            PacketFuse f = {w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance};
-            launch_trace_packet(sc->d, &P.pp, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats, w.stat_counters + 2, P.s,
-                                fuse_shade ? &f : nullptr);
-            shaded = fuse_shade;
-        } else {
-            launch_trace(sc->d, w.q[P.cur], P.qm, cam->t_min, cam->t_max, w.hb, want_stats,
-                         w.stat_counters + (P.depth == 0 ? 2 : 0), P.s);
-        }
-        HIPCHK(hipEventRecord(w.ev[3], P.s));
-        if (!shaded) launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], P.qm, w.hb, w.q[P.cur ^ 1], P.ob, d_count, w.path_radiance, P.s);
-        HIPCHK(hipMemcpyAsync(w.h_count, d_count, COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
-        HIPCHK(hipEventRecord(w.ev[4], P.s));
-        return RT_OK;
-    };
-    auto start_pass = [&](Pipe& P) -> int {
-        P.pass = next_pass++;
-        const uint32_t base = P.pass * per_pass;
-        P.nl = std::min(per_pass, opts->spp - base);
-        P.n = (uint32_t)(npix * P.nl);
-        P.pp = pp0;
-        P.pp.pass_base = base;
-        for (uint32_t g = 64; g > 1; g >>= 2)
-            if (g <= group_cap && P.nl % g == 0 && npix % (64u / g) == 0) { P.pp.group = g; break; }
-        P.depth = 0;
-        P.cur = 0;
-        P.qm = queue_map_single(P.n);
-        HIPCHK(hipEventRecord(P.w->ev[0], P.s));
-        if (!use_packet) {
-            launch_raygen(P.pp, P.qm, P.w->q[0], P.s);
-            st.launches++;
-        }
-        HIPCHK(hipEventRecord(P.w->ev[1], P.s));
-        P.state = Pipe::RUNNING;
-        return submit(P);
-    };
-    // radiance sums are added pass by pass in pass order (bit-reproducible), whichever pipe is first
-    auto accumulate = [&](Pipe& P, int pipe_index) -> int {
-        if (last_acc_pipe >= 0 && last_acc_pipe != pipe_index)
-            HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[last_acc_pipe], 0));
-        launch_accumulate(P.pp, P.w->path_radiance, P.nl, d_rgb_sum, P.s);
-        if (n_pipes > 1) HIPCHK(hipEventRecord(sc->ev_acc[pipe_index], P.s));
-        last_acc_pipe = pipe_index;
-        ++next_acc;
-        st.launches++;
-        st.passes++;
-        st.samples += (uint64_t)npix * P.nl;
-        ++done_passes;
-        P.state = Pipe::IDLE;
+        HIPCHK(hipEventSynchronize(w.ev[5]));
+        float ms[5];
+        for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], w.ev[i], w.ev[i + 1]));
+        st.seconds_trace_primary += ms[0] * 1e-3;
+        st.seconds_trace_bounce += ms[1] * 1e-3;
+        st.seconds_trace += (ms[0] + ms[1]) * 1e-3;
+        st.seconds_shade += (ms[2] + ms[4]) * 1e-3;
+        st.seconds_tail += ms[3] * 1e-3;
+        P.in_flight = false;
         return RT_OK;
     };
 
-    if ((rc = start_pass(pipes[0]))) return rc;
-    // The next pass starts when the one before it has finished its camera-ray launch: its camera rays (scalar-cache node
-    // fetches, coherent) then share the GPU with that pass's first bounce (vector gathers).  RT_HIP_STAGGER=<depth> for A/B:
-    // 0 / 1 / 2 / 3 -> 6747 / 6740 / 6590 / 6530 Msamples/s on the 1 M-triangle frame.
-    const char* sge = getenv("RT_HIP_STAGGER");
-    const uint32_t stagger_depth = sge ? (uint32_t)atoi(sge) : 1u;
-    int started = 1;                 // pipes started so far: pipe k+1 starts once pipe k is past its bulk, so they stay out of phase
-    while (done_passes < n_passes) {
-        bool progressed = false;
-        for (int k = 0; k < n_pipes; ++k) {
-            Pipe& P = pipes[k];
-            if (P.state == Pipe::IDLE) {
-                if (next_pass < n_passes && k < started) {
-                    if ((rc = start_pass(P))) return rc;
-                    progressed = true;
-                }
-                continue;
-            }
-            if (P.state == Pipe::WAIT_ACC) {
-                if (P.pass == next_acc) {
-                    if ((rc = accumulate(P, k))) return rc;
-                    progressed = true;
-                }
-                continue;
-            }
-            Workspace& w = *P.w;
-            // With two pipes the host must not sleep on one pipe's long bounce while the other pipe's short tail bounces
-            // finish one after the other: each pipe is polled, and served as soon as its bounce is done.
-            if (n_pipes > 1 && !poll_blocking) {
-                const hipError_t qe = hipEventQuery(w.ev[4]);
-                if (qe == hipErrorNotReady) continue;
-                if (qe != hipSuccess) HIPCHK(qe);
-            } else {
-                HIPCHK(hipEventSynchronize(w.ev[4]));
-            }
-            progressed = true;
-            HIPCHK(hipGetLastError());
-            float ms_t = 0.f, ms_s = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms_t, w.ev[2], w.ev[3]));
-            HIPCHK(hipEventElapsedTime(&ms_s, w.ev[3], w.ev[4]));
-            if (P.depth == 0) {
-                float ms_r = 0.f;
-                HIPCHK(hipEventElapsedTime(&ms_r, w.ev[0], w.ev[1]));
-                st.seconds_shade += ms_r * 1e-3;
-                st.seconds_trace_primary += ms_t * 1e-3;
-                st.primary_segments += P.n;
-            }
-            st.seconds_trace += ms_t * 1e-3;
-            st.seconds_shade += ms_s * 1e-3;
-            st.trace_launches++;
+    int prev_pipe = -1;
+    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+        const int k = (int)(pass % (uint32_t)n_pipes);
+        Pipe& P = pipes[k];
+        if ((rc = collect(P))) return rc;            // (also: the pipe's events are free to be recorded again)
+        Workspace& w = *P.w;
+        const uint32_t base = pass * per_pass;
+        const uint32_t nl = std::min(per_pass, opts->spp - base);
+        const uint32_t n = (uint32_t)(npix * nl);
+        PassParams pp = pp0;
+        pp.pass_base = base;
+        for (uint32_t g = 64; g > 1; g >>= 2)
+            if (g <= group_cap && nl % g == 0 && npix % (64u / g) == 0) { pp.group = g; break; }
+        const uint32_t scap = shard_cap_for(n);
+        const QueueGeom dense = {nullptr, scap, n};
+        uint32_t* cnt[2] = {w.counters, w.counters + COUNTER_BYTES / 4};
+        unsigned long long* sg_primary = w.stat_counters + STAT_GROUP * STAT_GROUP_PRIMARY;
+        unsigned long long* sg_bounce = w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE;
+        unsigned long long* sg_tail = w.stat_counters + STAT_GROUP * STAT_GROUP_TAIL;
+
+        // the coherent camera rays of this pass share the GPU with the incoherent bounces of the pass before it
+        if (stagger && prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
+        HIPCHK(hipEventRecord(w.ev[0], P.s));
+        // ---- depth 0: survivors -> q[1], counts cnt[0]
+        if (use_packet) {
+            PacketFuse f = {w.q[1], cnt[0], w.path_radiance};
+            launch_trace_packet(sc->d, &pp, w.q[0], dense, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s, fuse_shade ? &f : nullptr);
+            st.launches++;
+        } else {
+            launch_raygen(pp, dense, w.q[0], P.s);
+            launch_walk(sc->d, w.q[0], dense, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s);
             st.launches += 2;
-            st.ray_segments += P.n;
-            P.qm = queue_map_from_counts(P.ob, w.h_count, &P.n);
-            P.cur ^= 1;
-            P.depth++;
-            if (k == started - 1 && started < n_pipes && (P.depth >= stagger_depth || P.n == 0)) {
-                ++started;
-                if (next_pass < n_passes && (rc = start_pass(pipes[started - 1]))) return rc;
-            }
-            if (P.n == 0 || P.depth > cam->max_depth) {
-                P.state = Pipe::WAIT_ACC;
-                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
-            } else if ((rc = submit(P))) {
-                return rc;
-            }
         }
-        if (!progressed) std::this_thread::yield();
+        if (!fuse_shade) {
+            launch_shade(sc->d, pp, 0u, w.q[0], dense, n, w.hb, w.q[1], cnt[0], w.path_radiance, P.s);
+            st.launches++;
+        }
+        st.trace_launches++;
+        HIPCHK(hipEventRecord(w.ev[1], P.s));
+        HIPCHK(hipEventRecord(sc->ev_cam[k], P.s));
+        // ---- depths 1 .. tail_depth-1: stand-alone traversal + shading launches
+        int cur = 1, cset = 0;
+        uint32_t depth = 1;
+        bool ev2 = false;
+        for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
+            const QueueGeom qg = {cnt[cset], scap, 0u};
+            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_bounce, P.s);
+            st.trace_launches++;
+            st.bounce_launches++;
+            if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], P.s)); ev2 = true; }
+            if (depth >= 2) HIPCHK(hipMemsetAsync(cnt[cset ^ 1], 0, COUNTER_BYTES, P.s));      // (set last read two kernels ago)
+            launch_shade(sc->d, pp, depth, w.q[cur], qg, n, w.hb, w.q[cur ^ 1], cnt[cset ^ 1], w.path_radiance, P.s);
+            st.launches += 2;
+            cur ^= 1;
+            cset ^= 1;
+        }
+        if (!ev2) HIPCHK(hipEventRecord(w.ev[2], P.s));
+        HIPCHK(hipEventRecord(w.ev[3], P.s));
+        // ---- every remaining bounce inside one persistent launch
+        if (depth <= cam->max_depth) {
+            const QueueGeom qg = {cnt[cset], scap, 0u};
+            launch_walk_shade(sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance, want_stats, sg_tail, P.s);
+            st.launches++;
+        }
+        HIPCHK(hipEventRecord(w.ev[4], P.s));
+        // ---- radiance sums are added pass by pass in pass order (bit-reproducible), whichever pipe is first
+        if (prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[prev_pipe], 0));
+        launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, w.counters, (uint32_t)(2 * COUNTER_BYTES / 4), P.s);
+        HIPCHK(hipEventRecord(sc->ev_acc[k], P.s));
+        HIPCHK(hipEventRecord(w.ev[5], P.s));
+        HIPCHK(hipGetLastError());
+        st.launches++;
+        st.passes++;
+        st.samples += (uint64_t)n;
+        st.primary_segments += n;
+        P.in_flight = true;
+        prev_pipe = k;
     }
-    for (int k = 0; k < n_pipes; ++k) {
-        if (want_stats) HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, 128, hipMemcpyDeviceToHost, pipes[k].s));
-        HIPCHK(hipStreamSynchronize(pipes[k].s));
+    int first_err = RT_OK;
+    for (int k = 0; k < n_pipes; ++k) {      // drain every pipe, whatever happened on another one
+        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s);
+        if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].s);
+        if (e != hipSuccess && !first_err) {
+            (void)hipGetLastError();
+            first_err = fail(RT_ERR_HIP, "render: %s on pipe %d", hipGetErrorName(e), k);
+        }
     }
+    if (first_err) return first_err;
+    for (int k = 0; k < n_pipes; ++k)
+        if ((rc = collect(pipes[k]))) return rc;
     HIPCHK(hipGetLastError());
     st.seconds_total = now_s() - t0;
-    if (want_stats)
-        for (int k = 0; k < n_pipes; ++k) {
-            st.nodes_visited += pipes[k].w->h_stat[0] + pipes[k].w->h_stat[2];
-            st.prims_tested += pipes[k].w->h_stat[1] + pipes[k].w->h_stat[3];
-            st.nodes_visited_primary += pipes[k].w->h_stat[2];
-            st.prims_tested_primary += pipes[k].w->h_stat[3];
+    st.ray_segments = st.primary_segments;
+    for (int k = 0; k < n_pipes; ++k) {
+        const unsigned long long* h = pipes[k].w->h_stat;
+        const unsigned long long* hp = h + STAT_GROUP * STAT_GROUP_PRIMARY;
+        const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
+        const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
+        st.bounce_segments += hb_[STAT_SEGMENTS];
+        st.tail_segments += ht[STAT_SEGMENTS];
+        st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS];
+        if (want_stats) {
+            st.nodes_visited += hp[STAT_NODES] + hb_[STAT_NODES] + ht[STAT_NODES];
+            st.prims_tested += hp[STAT_PRIMS] + hb_[STAT_PRIMS] + ht[STAT_PRIMS];
+            st.nodes_visited_primary += hp[STAT_NODES];
+            st.prims_tested_primary += hp[STAT_PRIMS];
+            st.nodes_visited_bounce += hb_[STAT_NODES];
+            st.prims_tested_bounce += hb_[STAT_PRIMS];
+            st.wave_node_fetches_primary += hp[STAT_WAVE_NODES];
+            st.wave_prim_fetches_primary += hp[STAT_WAVE_PRIMS];
             if (getenv("RT_HIP_DEBUG_UTIL")) {      // bounce launches: lane steps / (64 x wave loop iterations)
-                const unsigned long long* h = pipes[k].w->h_stat;
                 fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
-                        k, h[0], h[5], h[4], h[4] ? (double)(h[0] + h[5]) / (64.0 * (double)h[4]) : 0.0);
+                        k, hb_[STAT_NODES], hb_[STAT_LEAVES], hb_[STAT_ITERS],
+                        hb_[STAT_ITERS] ? (double)(hb_[STAT_NODES] + hb_[STAT_LEAVES]) / (64.0 * (double)hb_[STAT_ITERS]) : 0.0);
 #ifdef RT_TIMING
-                const double it = (double)h[4];
+                const double it = (double)hb_[STAT_ITERS];
                 fprintf(stderr, "[rt_hip] pipe %d cycles per wave iteration: issue %.1f wait %.1f node %.1f prim %.1f refill %.1f; "
-                        "iterations with a node step %.3f, with a primitive step %.3f\n", k, h[8] / it, h[9] / it, h[10] / it, h[11] / it,
-                        h[12] / it, h[13] / it, h[14] / it);
+                        "iterations with a node step %.3f, with a primitive step %.3f\n", k, hb_[8] / it, hb_[9] / it, hb_[10] / it, hb_[11] / it,
+                        hb_[12] / it, hb_[13] / it, hb_[14] / it);
 #endif
             }
         }
+    }
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -788,6 +827,11 @@ void rt_scene_destroy(rt_scene* sc) {
         if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
         for (auto& e : sc->ev_acc)
             if (e) (void)hipEventDestroy(e);
+        for (auto& e : sc->ev_cam)
+            if (e) (void)hipEventDestroy(e);
+        if (sc->pv_sum) (void)hipFree(sc->pv_sum);
+        if (sc->pv_mean) (void)hipFree(sc->pv_mean);
+        if (sc->pv_rgba8) (void)hipFree(sc->pv_rgba8);
         for (void* p : sc->allocs) (void)hipFree(p);
     }
     (void)hipGetLastError();
@@ -822,17 +866,18 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     if ((rc = tmp.alloc(&d_hits, chunk))) return rc;
     hipStream_t stream = nullptr;
     const bool want_stats = stats != nullptr;
-    if (want_stats) HIPCHK(hipMemsetAsync(w.stat_counters, 0, 256, stream));
+    unsigned long long* sg = w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE;
+    if (want_stats) HIPCHK(hipMemsetAsync(w.stat_counters, 0, STAT_BYTES, stream));
     const double t0 = now_s();
     for (size_t off = 0; off < n; off += chunk) {
         const uint32_t m = (uint32_t)std::min(chunk, n - off);
         HIPCHK(hipMemcpyAsync(d_rays, rays + off, m * sizeof(rt_ray), hipMemcpyHostToDevice, stream));
-        const QueueMap qm = queue_map_single(m);
-        launch_prepare_rays(d_rays, qm, w.q[0], stream);
+        const QueueGeom qg = {nullptr, shard_cap_for(m), m};
+        launch_prepare_rays(d_rays, qg, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_trace(sc->d, w.q[0], qm, t_min, t_max, w.hb, want_stats, w.stat_counters, stream);
+        launch_walk(sc->d, w.q[0], qg, m, t_min, t_max, w.hb, want_stats, want_stats ? sg : nullptr, stream);
         HIPCHK(hipEventRecord(w.ev[1], stream));
-        launch_pack_hits(w.hb, qm, d_hits, stream);
+        launch_pack_hits(w.hb, qg, d_hits, stream);
         HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipGetLastError());
@@ -845,10 +890,14 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
         }
     }
     if (stats) {
-        HIPCHK(hipMemcpy(w.h_stat, w.stat_counters, 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(w.h_stat, w.stat_counters, STAT_BYTES, hipMemcpyDeviceToHost));
+        const unsigned long long* h = w.h_stat + STAT_GROUP * STAT_GROUP_BOUNCE;
         stats->ray_segments = n;
-        stats->nodes_visited = w.h_stat[0];
-        stats->prims_tested = w.h_stat[1];
+        stats->bounce_segments = h[STAT_SEGMENTS];
+        stats->nodes_visited = stats->nodes_visited_bounce = h[STAT_NODES];
+        stats->prims_tested = stats->prims_tested_bounce = h[STAT_PRIMS];
+        stats->seconds_trace_bounce = stats->seconds_trace;
+        stats->bounce_launches = stats->trace_launches;
         stats->seconds_total = now_s() - t0;
     }
     return RT_OK;
@@ -885,10 +934,10 @@ int rt_trace_closest_noalloc(const rt_scene* csc, const rt_ray* d_rays, size_t n
     hipStream_t stream = (hipStream_t)stream_;
     // Nothing has to start at zero: k_prepare_rays writes every queue slot the traversal reads, the traversal writes t and
     // prim of every one of them (bu / bv are not read by k_pack_hits), and no counter is involved (stats are off).
-    const QueueMap qm = queue_map_single((uint32_t)n);
-    launch_prepare_rays(d_rays, qm, q, stream);
-    launch_trace(sc->d, q, qm, t_min, t_max, hb, false, nullptr, stream);
-    launch_pack_hits(hb, qm, d_hits, stream);
+    const QueueGeom qg = {nullptr, shard_cap_for(n), (uint32_t)n};
+    launch_prepare_rays(d_rays, qg, q, stream);
+    launch_walk(sc->d, q, qg, (uint32_t)n, t_min, t_max, hb, false, nullptr, stream);
+    launch_pack_hits(hb, qg, d_hits, stream);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -924,13 +973,13 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.tiled = 0;
     pp.group = 1;
     hipStream_t stream = nullptr;
-    const QueueMap qm = queue_map_single((uint32_t)npix);
+    const QueueGeom qm = {nullptr, shard_cap_for(npix), (uint32_t)npix};
     launch_raygen(pp, qm, w.q[0], stream);
     // RT_HIP_PRIMARY_PACKET=1 (tests): the coherent-wave kernel that rt_render uses for camera rays, on the same rays
     if (getenv("RT_HIP_PRIMARY_PACKET") && packet_supported(sc->d))
-        launch_trace_packet(sc->d, nullptr, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream, nullptr);
+        launch_trace_packet(sc->d, nullptr, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, nullptr);
     else
-        launch_trace(sc->d, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, w.stat_counters, stream);
+        launch_walk(sc->d, w.q[0], qm, (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, nullptr, stream);
     launch_pack_hits(w.hb, qm, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {

@@ -126,13 +126,37 @@ __device__ __forceinline__ size_t slot_sample_to_pid(uint32_t slot, uint32_t loc
 }
 
 // ---- sharded queue addressing ----------------------------------------------------------------
-// wave: logical wave index (wave-uniform).  Returns whether this lane holds a live entry and its
-// physical slot.
-__device__ __forceinline__ bool queue_slot(const QueueMap& m, uint32_t wave, uint32_t lane, uint32_t& slot) {
-    const uint32_t shard = wave & (NSHARD - 1);
-    const uint32_t off = (wave / NSHARD) * 64u + lane;
-    slot = m.base[shard] + off;
-    return wave < m.n_waves && off < m.count[shard];
+// A wave's view of a queue: the shard counts are read once per wave from device memory (lane k keeps shard k's) and
+// looked up with v_readlane; a dense queue needs no memory at all.
+struct WaveQueue {
+    uint32_t cnt;          // lane k: live entries in shard k (sharded queues)
+    uint32_t n_waves;      // logical size of the queue in waves (wave-uniform)
+    uint32_t shard_cap, n_direct;
+    bool direct;
+    // lane = 0..63 of this wave; all 64 lanes call
+    __device__ __forceinline__ void load(const QueueGeom& g, uint32_t lane) {
+        shard_cap = g.shard_cap; n_direct = g.n_direct; direct = g.count == nullptr;
+        cnt = 0;
+        if (direct) { n_waves = (n_direct + 63u) >> 6; return; }
+        cnt = g.count[COUNT_STRIDE * lane];
+        uint32_t w = (cnt + 63u) >> 6;
+        for (int off = 32; off; off >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, off));
+        n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)w) * NSHARD;
+    }
+    // wave: logical wave index (wave-uniform).  Returns whether this lane holds a live entry and its physical slot.
+    __device__ __forceinline__ bool slot(uint32_t wave, uint32_t lane, uint32_t& i) const {
+        const uint32_t shard = wave & (NSHARD - 1);
+        const uint32_t off = (wave / NSHARD) * 64u + lane;
+        i = shard * shard_cap + off;
+        if (direct) return wave * 64u + lane < n_direct;
+        return wave < n_waves && off < (uint32_t)__builtin_amdgcn_readlane((int)cnt, __builtin_amdgcn_readfirstlane((int)shard));
+    }
+};
+// dense queues only (ray generation, packing): logical entry p -> physical slot
+__device__ __forceinline__ bool direct_slot(const QueueGeom& g, uint32_t p, uint32_t& i) {
+    const uint32_t wave = p >> 6;
+    i = (wave & (NSHARD - 1)) * g.shard_cap + (wave / NSHARD) * 64u + (p & 63u);
+    return p < g.n_direct;
 }
 
 // ---- primitives -----------------------------------------------------------------------------

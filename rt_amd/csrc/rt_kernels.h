@@ -25,43 +25,58 @@ struct PassParams {
     uint32_t group;                          // samples of a pixel per wave of camera rays (rt_device.h: pid_to_slot_sample)
 };
 
-// K0: primary rays for path ids [0, n_paths) -> queue
-void launch_raygen(const PassParams& pp, const QueueMap& qm, RayQueue q, hipStream_t s);
-// World::hit input for rt_trace_closest: normalise host rays into a queue (Ray::new)
-void launch_prepare_rays(const rt_ray* rays, const QueueMap& qm, RayQueue q, hipStream_t s);
-// K1: closest hit for queue[0, n)
-void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb,
-                  bool stats, unsigned long long* d_counters /* [2] */, hipStream_t s);
-// K1p: the same for coherent waves (camera rays in 8x8 tiles): wave-level packet traversal through the scalar cache
+// ---- device statistics: groups of STAT_GROUP u64 counters, one group per kind of launch ----------
+constexpr int STAT_GROUP = 16;
+enum { STAT_GROUP_PRIMARY = 0, STAT_GROUP_BOUNCE = 1, STAT_GROUP_TAIL = 2, STAT_GROUPS = 3 };
+enum {
+    STAT_NODES = 0,        // nodes visited, per lane          (collect_stats)
+    STAT_PRIMS = 1,        // primitives tested, per lane      (collect_stats)
+    STAT_SEGMENTS = 2,     // closest-hit queries completed    (always, k_walk)
+    STAT_ITERS = 3,        // wave loop iterations             (collect_stats)
+    STAT_LEAVES = 4,       // leaf steps                       (collect_stats)
+    STAT_WAVE_NODES = 5,   // node records fetched per WAVE by the coherent camera-ray kernel (collect_stats)
+    STAT_WAVE_PRIMS = 6    // primitive records fetched per wave by it
+};
+constexpr size_t STAT_BYTES = 512;                  // >= STAT_GROUPS * STAT_GROUP * 8
+
+// K0: primary rays for path ids [0, n) -> dense queue
+void launch_raygen(const PassParams& pp, const QueueGeom& qg, RayQueue q, hipStream_t s);
+// World::hit input for rt_trace_closest: normalise host rays into a dense queue (Ray::new)
+void launch_prepare_rays(const rt_ray* rays, const QueueGeom& qg, RayQueue q, hipStream_t s);
+// K1: closest hit for every entry of the queue -> hb.  n_upper: an upper bound of the entry count known to the host
+// (it only sizes the launch; the kernel reads the queue's counts from device memory).  d_counters: one statistics
+// group, or NULL.
+void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+                 bool stats, unsigned long long* d_counters, hipStream_t s);
+// K1 + K2-4, persistent: traces AND shades the queue's paths (entries at depth depth0), bounce after bounce inside
+// the kernel, until every path has ended (radiance slots written)
+void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
+                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, bool stats, unsigned long long* d_counters,
+                       hipStream_t s);
+// K1p: closest hit for coherent waves (camera rays; always a dense queue): wave-level packet traversal through the scalar cache
 // gen != NULL: the kernel generates the camera rays of that pass itself (K0 fused) and stores them in q
 // fuse != NULL (needs gen): the kernel also shades depth 0 and appends the survivors to fuse->q_out (the launch
 // of k_shade for depth 0 is then skipped; q and hb receive nothing but the barycentrics of triangle hits)
 struct PacketFuse {
     RayQueue q_out;
-    ShardBases out_bases;
     uint32_t* d_out_counts;
     double* d_path_radiance;
 };
 bool packet_supported(const DScene& S);
-void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
+void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueGeom& qg, double t_min, double t_max,
                          HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s, const PacketFuse* fuse = nullptr);
-// sharded-queue bookkeeping (host): a dense queue of n entries; the output bases of a shade launch
-// over `in`; the map of the queue that launch produced, from its NSHARD counters (32 u32 apart)
-QueueMap queue_map_single(uint32_t n);
-ShardBases shard_bases_for(const QueueMap& in);
-QueueMap queue_map_from_counts(const ShardBases& bases, const uint32_t* counts, uint32_t* total);
 constexpr size_t QUEUE_SLACK = 64 * NSHARD;   // physical slots beyond the path count a sharded queue may need
-constexpr size_t COUNTER_BYTES = 128 * NSHARD;
-// K2+K3+K4: shade (miss -> sky, hit -> scatter + Russian roulette) and compact survivors into q_out
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueMap& qm, HitBuf hb,
-                  RayQueue q_out, const ShardBases& out_bases, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s);
-// K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order
+constexpr size_t COUNTER_BYTES = COUNT_STRIDE * 4 * NSHARD;      // one set of shard counters
+// K2+K3+K4: shade (miss -> sky, hit -> scatter + Russian roulette) and compact survivors into q_out (same geometry)
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper, HitBuf hb,
+                  RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s);
+// K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order; clears n_zero u32 at d_zero_counts (may be NULL)
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local_samples,
-                       double* d_rgb_sum, hipStream_t s);
+                       double* d_rgb_sum, uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s);
 // K5b: mean = sum / total_spp
 void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
-// hits (SoA) -> rt_hit[]; slot i holds path id pid[i] (identity for prepare_rays / first trace)
-void launch_pack_hits(HitBuf hb, const QueueMap& qm, rt_hit* out, hipStream_t s);
-void launch_pack_rays(RayQueue q, const QueueMap& qm, rt_ray* out, hipStream_t s);
+// hits (SoA, dense queue) -> rt_hit[]
+void launch_pack_hits(HitBuf hb, const QueueGeom& qg, rt_hit* out, hipStream_t s);
+void launch_pack_rays(RayQueue q, const QueueGeom& qg, rt_ray* out, hipStream_t s);
 
 }  // namespace rt

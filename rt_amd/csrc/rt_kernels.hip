@@ -1,14 +1,19 @@
 // rt_kernels.hip — wavefront path-tracing kernels for gfx950 (wave64).
 //
-//   K0 k_raygen      Camera::get_ray                     src/camera.rs:231-254, :367-371, :140-165
-//   K1 k_trace       World::hit over the BVH             src/hittable.rs:135-149, :318-365, :408-495
-//   K2-4 k_shade     sky on miss, Material::scatter,     src/hittable.rs:84-93, src/material.rs:94-179,
-//                    russian_roulette, compaction        src/camera.rs:280-313
-//   K5 k_accumulate / k_resolve   render_pixel's mean    src/camera.rs:315-325
+//   K0 k_raygen        Camera::get_ray                     src/camera.rs:231-254, :367-371, :140-165
+//   K1 k_walk          World::hit over the BVH             src/hittable.rs:135-149, :318-365, :408-495
+//      k_trace_packet  the same for coherent camera rays (+ K0 and depth-0 shading fused in)
+//   K2-4 k_shade       sky on miss, Material::scatter,     src/hittable.rs:84-93, src/material.rs:94-179,
+//                      russian_roulette, compaction        src/camera.rs:280-313
+//      k_walk<SHADE>   K1 + K2-4 in one persistent kernel: a lane traces, shades and goes on with the scattered
+//                      ray until its path ends, then takes the next path from the queue (the raycast recursion of
+//                      src/camera.rs:296-313 unrolled per lane)
+//   K5 k_accumulate / k_resolve   render_pixel's mean      src/camera.rs:315-325
 //
 // One lane = one path.  Between bounces the survivors are compacted into the next queue with a
-// wave64 ballot + one atomic per wave.  Radiance is written once per path into its own slot and
-// summed per pixel in sample order, so a render is bit-reproducible.
+// wave64 ballot + one atomic per wave; every consumer reads the queue's entry counts from device
+// memory, so the host queues the kernels of a whole pass without a round trip.  Radiance is written
+// once per path into its own slot and summed per pixel in sample order, so a render is bit-reproducible.
 #include "rt_kernels.h"
 
 #include <algorithm>
@@ -49,10 +54,10 @@ __device__ __forceinline__ void camera_ray(const PassParams& pp, uint32_t pid, D
     dir = normalize(sub(ps, origin));                    // Ray::new normalises
 }
 
-__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, RayQueue q) {
+__global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueGeom qg, RayQueue q) {
     const uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;       // logical entry = path id
     uint32_t slot = 0;
-    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(pid >> 6), threadIdx.x & 63u, slot)) return;
+    if (!direct_slot(qg, pid, slot)) return;
     D3 origin, dir;
     camera_ray(pp, pid, origin, dir);
     q.o[0][slot] = origin.x; q.o[1][slot] = origin.y; q.o[2][slot] = origin.z;
@@ -60,10 +65,10 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueMap qm, Ra
     q.pid[slot] = pid;                                   // (throughput starts at 1: k_shade does not read it at depth 0)
 }
 
-__global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, QueueMap qm, RayQueue q) {
+__global__ __launch_bounds__(BLOCK) void k_prepare_rays(const rt_ray* rays, QueueGeom qg, RayQueue q) {
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t i = 0;
-    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
+    if (!direct_slot(qg, p, i)) return;
     D3 o = ld3(rays[p].o), d = normalize(ld3(rays[p].d));
     q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
     q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
@@ -229,115 +234,30 @@ constexpr int TRACE_BLOCK = 64;
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 1
 #endif
-template <class BoxT, bool STATS, int STACK>
-__global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
-                                                        HitBuf hb, unsigned long long* counters) {
-    __shared__ uint32_t stack[STACK][TRACE_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    uint32_t i = 0;
-    const bool active = queue_slot(qm, blockIdx.x, tid, i);
-    D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
-    if (active) {
-        o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
-        d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
-    }
-    BoxT rb;
-    rb.init(S, o, d, t_min, t_max);
-    double best = t_max, bu = 0.0, bv = 0.0;
-    uint32_t prim = RT_MISS;
-    uint32_t cur = active ? S.root : REF_EMPTY;
-    int sp = 0;
-    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
 
-    // Leaf work (f64 primitive tests) is several times the cost of a node step, and in a plain
-    // per-lane if/else loop it would run on almost every iteration for a handful of lanes.  Lanes
-    // that reach a leaf therefore wait until LEAF_BATCH lanes hold one (or no lane can descend any
-    // further); only then the wave intersects leaves.  (LEAF_BATCH = 1 is the plain loop, 64 the
-    // classic while-while, which idles too long here.)
-#ifndef RT_LEAF_T
-#define RT_LEAF_T 1
-#endif
-    constexpr int LEAF_BATCH = RT_LEAF_T;
-    for (;;) {
-        const bool at_node = !(cur & REF_LEAF);                 // REF_EMPTY has the leaf bit set
-        const bool at_leaf = !at_node && cur != REF_EMPTY;
-        const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(at_leaf);
-        if (!(m_node | m_leaf)) break;
-        if (STATS) ++n_iters;
-        if (at_node) {
-            typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
-            uint32_t cl, cr;
-            rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
-            if (STATS) ++n_nodes;
-            bool hl = rb.test(lo_l, hi_l, tl);
-            bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                stack[sp++][tid] = left_first ? cr : cl;
-                cur = left_first ? cl : cr;
-            } else if (hl) {
-                cur = cl;
-            } else if (hr) {
-                cur = cr;
-            } else {
-                cur = sp ? stack[--sp][tid] : REF_EMPTY;
-            }
-        }
-        if (at_leaf && (__popcll(m_leaf) >= LEAF_BATCH || !m_node)) {
-            const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
-            if (STATS) { n_prims += count; ++n_leaves; }
-            if (cur & REF_SPHERE) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const SphGeom* g = &S.sphs[first + k];
-                    double t;
-                    if (sph_test(ld3(g->c), g->r, ld3(g->rot2), o, d, t_min, best, t)) { best = t; prim = g->prim; rb.nearest(best); }
-                }
-            } else {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const TriGeom* g = &S.tris[first + k];
-                    double t, u, v;
-                    if (tri_test(ld3(g->a), ld3(g->e1), ld3(g->e2), o, d, t_min, best, t, u, v)) {
-                        best = t; prim = g->prim; bu = u; bv = v;
-                        rb.nearest(best);
-                    }
-                }
-            }
-            cur = sp ? stack[--sp][tid] : REF_EMPTY;
-        }
-    }
-    if (active) {
-        hb.t[i] = prim == RT_MISS ? 0.0 : best;
-        hb.prim[i] = prim;
-        hb.bu[i] = bu;
-        hb.bv[i] = bv;
-    }
-    if (STATS) {
-        unsigned long long a = n_nodes, b = n_prims, c = n_leaves;
-        for (int off = 32; off; off >>= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-            c += __shfl_xor(c, off);
-        }
-        if ((tid & 63u) == 0) {
-            atomicAdd(&counters[0], a);
-            atomicAdd(&counters[1], b);
-            atomicAdd(&counters[4], (unsigned long long)n_iters);     // wave loop iterations (debug: lane utilisation)
-            atomicAdd(&counters[5], c);                               // leaf visits
-        }
-    }
-}
+__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
+                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
+                                           double* path_radiance, D3& no, D3& nd, D3& nthr);
+__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, uint32_t shard_cap,
+                                             uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr);
 
-// K1w — per-lane traversal of the BVH4 (Node4, 16-bit grid); the kernel bounce rays use when the scene has
-// one.  A step fetches one 64-byte node, tests its four child boxes in grid space (Box16), sorts the hit
-// children by entry distance (5 compare-exchanges), descends into the nearest and pushes the others
-// far-to-near: half the node fetches and dependent steps of the BVH2 walk per ray.  The box tests only
-// cull and the primitive tests are the same exact f64 ones, so (prim, t) do not change.  BoxT = Box32 walks the
-// f32 variant of the tree (Node4f, 128-byte nodes, world space) for scenes without a usable grid.
+// K1 — per-lane traversal, the kernel of every incoherent ray.  WIDTH = 4 walks the BVH4 (Node4 on the 16-bit grid
+// with BoxT = Box16; Node4f, 128-byte nodes with f32 boxes in world space, with BoxT = Box32, for scenes whose grid would
+// be too coarse): a step fetches one node, tests its four child boxes, sorts the hit children by entry distance (5
+// compare-exchanges), descends into the nearest and pushes the others far-to-near — half the node fetches and dependent
+// steps of a BVH2 walk.  WIDTH = 2 walks the BVH2 in any box format (Node16 / Node32 / Node64: scenes that need f64
+// boxes or have no BVH4, and A/B runs).  The box tests only cull and the primitive tests are the exact f64 ones, so
+// (prim, t) do not depend on the tree or the format.
 // Lane refill: wave p owns the 64-entry chunks p, p + P, p + 2P, ... (P = gridDim.x) of the queue.  When
 // RT_REFILL_T or more lanes are idle and chunks are left, the finished lanes store their hits and take the
 // next rays.  Launched with P = number of chunks it is the plain one-chunk-per-wave kernel; launched with
 // P = resident waves it is persistent.  Every wave exits: chunks are consumed monotonically and the loop
-// ends when none is left and no lane holds a ray.  STACK >= S.stack4 (checked by the launcher).
+// ends when none is left and no lane holds a ray.  The stack (dynamic LDS, `stack_entries` rows of 64 lanes) holds
+// S.stack4 (WIDTH 4) / S.bvh_depth (WIDTH 2) entries per lane (checked by the launcher).
+// SHADE: the lane does not store its hit but shades it (shade_path: sky, scatter, Russian roulette) and, if the path
+// goes on, traces the scattered ray at once; it takes a new path from the queue only when its own has ended.  One launch
+// runs every remaining bounce of a pass: no queue traffic, no launch per bounce, no host in the loop.  Every wave
+// still exits: a path's depth grows with every shade and shade_path ends it at max_depth at the latest.
 #ifndef RT_REFILL_T
 #define RT_REFILL_T 24
 #endif
@@ -346,24 +266,36 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace(DScene S,
 #else
 #define RT_T4_ATTR
 #endif
-template <class BoxT, bool STATS, int STACK>
-__global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trace4(DScene S, RayQueue q, QueueMap qm, double t_min, double t_max,
-                                                                         HitBuf hb, unsigned long long* counters) {
-    __shared__ uint32_t stack[STACK][TRACE_BLOCK];
+struct WalkShade {
+    PassParams pp;
+    uint32_t depth0;            // depth of the queue's entries
+    uint32_t _pad;
+    double* path_radiance;
+};
+template <class BoxT, int WIDTH, bool STATS, bool SHADE>
+__global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
+                                                                       HitBuf hb, unsigned long long* counters, WalkShade sh) {
+    extern __shared__ uint32_t stack_mem[];
+    uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_chunks = qm.n_waves, stride = gridDim.x;
+    WaveQueue wq;
+    wq.load(qg, tid);
+    const uint32_t n_chunks = wq.n_waves, stride = gridDim.x;
     uint32_t next_chunk = blockIdx.x, chunk = 0, chunk_pos = 64;      // wave-uniform
     bool busy = false;                                                // this lane holds a ray
     uint32_t slot = 0;
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
-    constexpr bool F32_NODES = std::is_same<BoxT, Box32>::value;      // Node4f (128 B) instead of Node4 (64 B)
+    D3 thr = mk(1, 1, 1);                                             // SHADE: path throughput, path id, depth of the ray in flight
+    uint32_t pid = 0, depth = 0;
+    constexpr bool W4 = WIDTH == 4;
+    constexpr bool F32_NODES = W4 && std::is_same<BoxT, Box32>::value;      // Node4f (128 B) instead of Node4 (64 B)
     BoxT rb;
     rb.init(S, o, d, t_min, t_max);
     double best = t_max;                                              // (barycentrics go to hb when a hit is accepted:
     uint32_t prim = RT_MISS;                                          //  four registers fewer across the loop)
     uint32_t cur = REF_EMPTY;
     int sp = 0;
-    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0;
+    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0, n_seg = 0;
 #ifdef RT_TIMING
     unsigned long long tm_issue = 0, tm_wait = 0, tm_node = 0, tm_prim = 0, tm_refill = 0, tm_n_node = 0, tm_n_prim = 0, tm_last = clock64();
 #define RT_STAMP(acc) { const unsigned long long now_ = clock64(); acc += now_ - tm_last; tm_last = now_; }
@@ -376,11 +308,34 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         const bool at_leaf = !at_node && cur != REF_EMPTY;
         const unsigned long long m_live = __ballot(at_node || at_leaf);
         bool more = chunk_pos < 64u || next_chunk < n_chunks;
-        if (!m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T)) {
+        bool service;
+        if (SHADE) {
+            // lanes with something to do in the block below: finished traversals (to shade), and idle lanes while rays are left
+            const int n_fin = __popcll(__ballot(busy && cur == REF_EMPTY));
+            const int n_idle = more ? __popcll(__ballot(!busy)) : 0;
+            service = !m_live || n_fin + n_idle >= RT_REFILL_T;
+        } else {
+            service = !m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T);
+        }
+        if (service) {
             if (busy && cur == REF_EMPTY) {                           // retire
-                hb.t[slot] = prim == RT_MISS ? 0.0 : best;
-                hb.prim[slot] = prim;
-                busy = false;
+                ++n_seg;
+                if (SHADE) {
+                    D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
+                    const bool alive = shade_path(S, sh.pp, depth, pid, slot, o, d, thr, prim, best, hb, sh.path_radiance, no, nd, nthr);
+                    if (alive) {                                      // Camera::raycast's recursion (src/camera.rs:303): the same lane goes on
+                        o = no; d = nd; thr = nthr; ++depth;
+                        rb.init(S, o, d, t_min, t_max);
+                        best = t_max; prim = RT_MISS;
+                        cur = S.root; sp = 0;
+                    } else {
+                        busy = false;
+                    }
+                } else {
+                    hb.t[slot] = prim == RT_MISS ? 0.0 : best;
+                    hb.prim[slot] = prim;
+                    busy = false;
+                }
             }
             while (more) {                                            // refill
                 const unsigned long long m_idle = __ballot(!busy);
@@ -391,10 +346,15 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
                 const uint32_t take = min((uint32_t)__popcll(m_idle), 64u - chunk_pos);
                 uint32_t i = 0;
-                if (!busy && rank < take && queue_slot(qm, chunk, chunk_pos + rank, i)) {
+                if (!busy && rank < take && wq.slot(chunk, chunk_pos + rank, i)) {
                     slot = i; busy = true;
                     o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
                     d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+                    if (SHADE) {
+                        thr = mk(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
+                        pid = q.pid[i];
+                        depth = sh.depth0;
+                    }
                     rb.init(S, o, d, t_min, t_max);
                     best = t_max; prim = RT_MISS;
                     cur = S.root; sp = 0;
@@ -410,17 +370,19 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         // One dependent memory round trip per iteration for every lane: a node lane fetches its 64-byte node,
         // a leaf lane ONE primitive of its leaf (80-byte triangle / 64-byte sphere); a leaf of n primitives
         // takes n iterations (the reference keeps count and first, so it is advanced in place).  All loads are
-        // issued before anything waits, whatever mix of node and leaf lanes the wave holds.
+        // issued before anything waits, whatever mix of node and leaf lanes the wave holds.  (The BVH2 walk loads its
+        // node inside the node step instead: it is the fallback, not the fast path.)
         const uint32_t first = cur & REF_FIRST_MASK;
         const bool tri_leaf = at_leaf && !(cur & REF_SPHERE);
+        const bool node_load = W4 && at_node;
         // base + index * stride with the three selected separately: one multiply-add instead of three masked address paths
-        const char* base_ = at_node ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
-                                    : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
-        const uint32_t stride_ = at_node ? (uint32_t)(F32_NODES ? sizeof(Node4f) : sizeof(Node4)) : tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
+        const char* base_ = node_load ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
+                                      : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
+        const uint32_t stride_ = node_load ? (uint32_t)(F32_NODES ? sizeof(Node4f) : sizeof(Node4)) : tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
         const char* src = base_ + (uint64_t)first * stride_;            // (node indices are below 2^28 as well)
         const uint4* p = reinterpret_cast<const uint4*>(src);
         uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
-        if (at_node || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
+        if (node_load || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
         if (tri_leaf || (F32_NODES && at_node)) e = p[4];
         if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
 #ifdef RT_TIMING
@@ -432,41 +394,63 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
 #endif
         if (at_node) {
             if (STATS) ++n_nodes;
-            const uint32_t w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
-                                    r.x, r.y, r.z, r.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
-            uint32_t ref[4] = {r.x, r.y, r.z, r.w};
-            if (F32_NODES) { ref[0] = g.x; ref[1] = g.y; ref[2] = g.z; ref[3] = g.w; }
-            float key[4];
+            if constexpr (W4) {
+                const uint32_t w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w,
+                                        r.x, r.y, r.z, r.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+                uint32_t ref[4] = {r.x, r.y, r.z, r.w};
+                if (F32_NODES) { ref[0] = g.x; ref[1] = g.y; ref[2] = g.z; ref[3] = g.w; }
+                float key[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float tn = 0.f;
-                bool h;
-                if constexpr (F32_NODES) {          // child k owns floats 6k .. 6k+5
-                    const bool neg[3] = {rb.ix < 0.f, rb.iy < 0.f, rb.iz < 0.f};
-                    float near[3], far[3];
-                    for (int j = 0; j < 3; ++j) {
-                        const float lo = __uint_as_float(w[6 * k + j]), hi = __uint_as_float(w[6 * k + 3 + j]);
-                        near[j] = neg[j] ? hi : lo; far[j] = neg[j] ? lo : hi;
+                for (int k = 0; k < 4; ++k) {
+                    float tn = 0.f;
+                    bool h;
+                    if constexpr (F32_NODES) {          // child k owns floats 6k .. 6k+5
+                        const bool neg[3] = {rb.ix < 0.f, rb.iy < 0.f, rb.iz < 0.f};
+                        float near[3], far[3];
+                        for (int j = 0; j < 3; ++j) {
+                            const float lo = __uint_as_float(w[6 * k + j]), hi = __uint_as_float(w[6 * k + 3 + j]);
+                            near[j] = neg[j] ? hi : lo; far[j] = neg[j] ? lo : hi;
+                        }
+                        const bool hh = rb.test_picked(near, far, tn);
+                        h = hh & (ref[k] != REF_EMPTY);
+                    } else if constexpr (std::is_same<BoxT, Box16>::value) {
+                        // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5.
+                        // all four children are tested without a branch on the empty ones (an empty slot's box is all zeros):
+                        // four masked regions per node step cost more than the arithmetic they skip
+                        const bool hh = rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
+                        h = hh & (ref[k] != REF_EMPTY);
+                    } else {
+                        h = false;                      // (no BVH4 with f64 boxes exists: never instantiated at run time)
                     }
-                    const bool hh = rb.test_picked(near, far, tn);
-                    h = hh & (ref[k] != REF_EMPTY);
-                } else {                            // u16 number j of the node sits in word j/2, half j%2; child k owns numbers 6k .. 6k+5
-                    // all four children are tested without a branch on the empty ones (an empty slot's box is all zeros):
-                    // four masked regions per node step cost more than the arithmetic they skip
-                    const bool hh = rb.test_child(w[3 * k], w[3 * k + 1], w[3 * k + 2], tn);
-                    h = hh & (ref[k] != REF_EMPTY);
+                    key[k] = h ? tn : INFINITY;                 // misses carry no child: wherever the sort leaves them (a NaN entry
+                    ref[k] = h ? ref[k] : REF_EMPTY;            // distance compares false both ways), they are skipped below
                 }
-                key[k] = h ? tn : INFINITY;                 // misses carry no child: wherever the sort leaves them (a NaN entry
-                ref[k] = h ? ref[k] : REF_EMPTY;            // distance compares false both ways), they are skipped below
-            }
 #define RT_CE(x, y) { const bool sw = key[y] < key[x]; const float kx = sw ? key[y] : key[x], ky = sw ? key[x] : key[y]; \
                       const uint32_t rx = sw ? ref[y] : ref[x], ry = sw ? ref[x] : ref[y]; key[x] = kx; key[y] = ky; ref[x] = rx; ref[y] = ry; }
-            RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+                RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-            if (ref[3] != REF_EMPTY) stack[sp++][tid] = ref[3];
-            if (ref[2] != REF_EMPTY) stack[sp++][tid] = ref[2];
-            if (ref[1] != REF_EMPTY) stack[sp++][tid] = ref[1];
-            cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
+                if (ref[3] != REF_EMPTY) stack[sp++][tid] = ref[3];
+                if (ref[2] != REF_EMPTY) stack[sp++][tid] = ref[2];
+                if (ref[1] != REF_EMPTY) stack[sp++][tid] = ref[1];
+                cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
+            } else {
+                typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
+                uint32_t cl, cr;
+                rb.fetch(S, cur, lo_l, hi_l, lo_r, hi_r, cl, cr);
+                const bool hl = rb.test(lo_l, hi_l, tl);
+                const bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
+                if (hl && hr) {
+                    const bool left_first = tl <= tr;
+                    stack[sp++][tid] = left_first ? cr : cl;
+                    cur = left_first ? cl : cr;
+                } else if (hl) {
+                    cur = cl;
+                } else if (hr) {
+                    cur = cr;
+                } else {
+                    cur = sp ? stack[--sp][tid] : REF_EMPTY;
+                }
+            }
         }
 #ifdef RT_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -498,6 +482,11 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
         RT_STAMP(tm_prim)
 #endif
     }
+    if (counters) {                                                   // (null: the allocation-free entry point keeps no counters)
+        unsigned long long sg = n_seg;
+        for (int off = 32; off; off >>= 1) sg += __shfl_xor(sg, off);
+        if (tid == 0 && sg) atomicAdd(&counters[STAT_SEGMENTS], sg);
+    }
     if (STATS) {
         unsigned long long a = n_nodes, b = n_prims, c = n_leaves;
         for (int off = 32; off; off >>= 1) {
@@ -505,11 +494,11 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_trac
             b += __shfl_xor(b, off);
             c += __shfl_xor(c, off);
         }
-        if ((tid & 63u) == 0) {
-            atomicAdd(&counters[0], a);
-            atomicAdd(&counters[1], b);
-            atomicAdd(&counters[4], (unsigned long long)n_iters);
-            atomicAdd(&counters[5], c);
+        if (tid == 0) {
+            atomicAdd(&counters[STAT_NODES], a);
+            atomicAdd(&counters[STAT_PRIMS], b);
+            atomicAdd(&counters[STAT_ITERS], (unsigned long long)n_iters);
+            atomicAdd(&counters[STAT_LEAVES], c);
 #ifdef RT_TIMING
             atomicAdd(&counters[8], tm_issue); atomicAdd(&counters[9], tm_wait); atomicAdd(&counters[10], tm_node);
             atomicAdd(&counters[11], tm_prim); atomicAdd(&counters[12], tm_refill); atomicAdd(&counters[13], tm_n_node);
@@ -540,12 +529,6 @@ __device__ __forceinline__ u32x4 uload4(const void* p) { return *(const RT_AS4 u
 struct PacketEntry { uint32_t ref, mask_lo, mask_hi; };
 
 
-__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
-                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
-                                           double* path_radiance, D3& no, D3& nd, D3& nthr);
-__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, const ShardBases& ob,
-                                             uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr);
-
 // GEN: the wave generates its own camera rays (K0 fused in: saves the queue round trip of k_raygen)
 // and stores them for k_shade.
 // FUSE (with GEN): the wave also shades its hits (depth 0) and appends the survivors to qo, so neither the
@@ -557,13 +540,13 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t
 #endif
 #define RT_PK_ATTR __attribute__((amdgpu_waves_per_eu(RT_PK_WAVES, RT_PK_WAVES)))
 template <bool STATS, bool GEN, bool FUSE>
-__global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueMap qm, double t_min,
+__global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene S, PassParams pp, RayQueue q, QueueGeom qg, double t_min,
                                                                double t_max, HitBuf hb, unsigned long long* counters,
-                                                               RayQueue qo, ShardBases ob, uint32_t* out_counts, double* path_radiance) {
+                                                               RayQueue qo, uint32_t* out_counts, double* path_radiance) {
     __shared__ PacketEntry stack[BVH_MAX_DEPTH];
     const uint32_t lane = threadIdx.x;
     uint32_t i = 0;
-    const bool active = queue_slot(qm, blockIdx.x, lane, i);
+    const bool active = direct_slot(qg, blockIdx.x * TRACE_BLOCK + lane, i);      // camera rays: always a dense queue
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
     if (active) {
         if (GEN) {
@@ -583,7 +566,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
     rb.init(S, o, d, t_min, t_max);
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
-    uint32_t n_nodes = 0, n_prims = 0;
+    uint32_t n_nodes = 0, n_prims = 0, w_nodes = 0, w_prims = 0;      // per lane / per wave (records the wave fetched)
     unsigned long long mask = __ballot(active);
     // Camera rays of a few neighbouring pixels nearly always agree on the sign of each direction component; then the
     // near and far plane of every box are the same for the whole wave and are picked with scalar selects.
@@ -630,6 +613,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             const bool hl = mine & tl_ok;
             const bool hr = mine & tr_ok & (cr != REF_EMPTY);
             if (STATS && mine) ++n_nodes;
+            if (STATS) ++w_nodes;
             const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
             if (ml && mr) {
                 // near child first, by majority of the lanes that care
@@ -656,6 +640,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         } else {
             const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
             if (STATS && mine) n_prims += count;
+            if (STATS) w_prims += count;
             if (cur & REF_SPHERE) {
                 for (uint32_t k = 0; k < count; ++k) {
                     const u32x16 g = uload16(&S.sphs[first + k]);
@@ -692,7 +677,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             if (prim != RT_MISS) { hb.bu[i] = bu; hb.bv[i] = bv; }      // read back only by textured triangles
             alive = shade_path(S, pp, 0u, pid, i, o, d, mk(1.0, 1.0, 1.0), prim, best, hb, path_radiance, no, nd, nthr);
         }
-        queue_append(alive, blockIdx.x, lane, qo, ob, out_counts, pid, no, nd, nthr);
+        queue_append(alive, blockIdx.x, lane, qo, qg.shard_cap, out_counts, pid, no, nd, nthr);
     } else if (active) {
         hb.t[i] = prim == RT_MISS ? 0.0 : best;
         hb.prim[i] = prim;
@@ -706,8 +691,10 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             b += __shfl_xor(b, off);
         }
         if (lane == 0) {
-            atomicAdd(&counters[0], a);
-            atomicAdd(&counters[1], b);
+            atomicAdd(&counters[STAT_NODES], a);
+            atomicAdd(&counters[STAT_PRIMS], b);
+            atomicAdd(&counters[STAT_WAVE_NODES], (unsigned long long)w_nodes);
+            atomicAdd(&counters[STAT_WAVE_PRIMS], (unsigned long long)w_prims);
         }
     }
 }
@@ -815,14 +802,14 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
 
 // K4: survivors of logical wave `wave` are appended to its output shard: wave64 ballot + prefix count, one
 // atomic per wave on that shard's counter (counters sit 128 B apart).  Called by all 64 lanes.
-__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, const ShardBases& ob,
+__device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, uint32_t shard_cap,
                                              uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr) {
     const unsigned long long mask = __ballot(alive);
     if (mask) {
         const uint32_t shard = wave & (NSHARD - 1);
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(out_counts + 32 * shard, (uint32_t)__popcll(mask));
-        base = __shfl(base, 0) + ob.base[shard];
+        if (lane == 0) base = atomicAdd(out_counts + COUNT_STRIDE * shard, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0) + shard * shard_cap;
         if (alive) {
             const uint32_t j = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             qo.o[0][j] = no.x; qo.o[1][j] = no.y; qo.o[2][j] = no.z;
@@ -833,13 +820,18 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueMap qm,
-                                                 HitBuf hb, RayQueue qo, ShardBases ob, uint32_t* out_counts,
-                                                 double* path_radiance) {
+// One launched wave per logical wave of the queue.  The host does not know how many entries the queue holds (the
+// counts stay on the device), so it launches for an upper bound and the waves beyond the queue's end leave at once.
+// (A persistent grid-stride form of this kernel needs 147 instead of 90 VGPRs: three instead of five waves per SIMD.)
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
+                                                 HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    WaveQueue wq;
+    wq.load(qg, lane);
+    if (wave >= wq.n_waves) return;
     uint32_t i = 0;
-    const bool active = queue_slot(qm, wave, lane, i);
+    const bool active = wq.slot(wave, lane, i);
     bool alive = false;
     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
     uint32_t pid = 0;
@@ -853,15 +845,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
         const double t = prim == RT_MISS ? 0.0 : hb.t[i];
         alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, t, hb, path_radiance, no, nd, nthr);
     }
-    queue_append(alive, wave, lane, qo, ob, out_counts, pid, no, nd, nthr);
+    queue_append(alive, wave, lane, qo, qg.shard_cap, out_counts, pid, no, nd, nthr);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K5 — per-pixel sum in sample order, and the final mean
 // ---------------------------------------------------------------------------------------------
+// zero_counts (may be null): the pass's queue counters, cleared here for the next pass on this workspace — every kernel
+// that reads or appends to them has finished by the time the pass's sums are taken.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radiance, uint32_t n_pixels, uint32_t W, uint32_t H,
-                                                      uint32_t tiled, uint32_t group, uint32_t n_local, double* rgb_sum) {
+                                                      uint32_t tiled, uint32_t group, uint32_t n_local, double* rgb_sum,
+                                                      uint32_t* zero_counts, uint32_t n_zero) {
     uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (zero_counts && slot < n_zero) zero_counts[slot] = 0u;
     if (slot >= n_pixels) return;
     const uint32_t pixel = slot_to_pixel(slot, W, H, tiled);
     double r = rgb_sum[3 * (size_t)pixel], g = rgb_sum[3 * (size_t)pixel + 1], b = rgb_sum[3 * (size_t)pixel + 2];
@@ -877,18 +873,18 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* me
     if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, QueueMap qm, rt_hit* out) {
+__global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, QueueGeom qg, rt_hit* out) {
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t i = 0;
-    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
+    if (!direct_slot(qg, p, i)) return;
     rt_hit h;
     h.t = hb.t[i]; h.prim = hb.prim[i]; h._pad = 0;
     out[p] = h;
 }
-__global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, QueueMap qm, rt_ray* out) {
+__global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, QueueGeom qg, rt_ray* out) {
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t i = 0;
-    if (!queue_slot(qm, __builtin_amdgcn_readfirstlane(p >> 6), threadIdx.x & 63u, i)) return;
+    if (!direct_slot(qg, p, i)) return;
     rt_ray r;
     for (int k = 0; k < 3; ++k) { r.o[k] = q.o[k][i]; r.d[k] = q.d[k][i]; }
     out[p] = r;
@@ -899,184 +895,138 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, QueueMap qm, rt
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-void launch_raygen(const PassParams& pp, const QueueMap& qm, RayQueue q, hipStream_t s) {
-    if (!qm.n_waves) return;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, pp, qm, q);
+void launch_raygen(const PassParams& pp, const QueueGeom& qg, RayQueue q, hipStream_t s) {
+    if (!qg.n_direct) return;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, pp, qg, q);
 }
-void launch_prepare_rays(const rt_ray* rays, const QueueMap& qm, RayQueue q, hipStream_t s) {
-    if (!qm.n_waves) return;
-    hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, rays, qm, q);
+void launch_prepare_rays(const rt_ray* rays, const QueueGeom& qg, RayQueue q, hipStream_t s) {
+    if (!qg.n_direct) return;
+    hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, rays, qg, q);
 }
-// waves the chip holds at once of a kernel (one wave per workgroup), queried once per instance
+// waves the chip holds at once of a kernel (one wave per workgroup) with `lds` bytes of dynamic LDS
 template <class K>
-static unsigned resident_waves(K kernel) {
+static unsigned resident_waves(K kernel, size_t lds) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TRACE_BLOCK, lds) != hipSuccess || per_cu < 1)
         return 256u * 8u;
     return (unsigned)pr.multiProcessorCount * (unsigned)per_cu;
 }
-// the BVH4 kernel refills by default (RT_HIP_NO_REFILL=1 launches it one chunk per wave)
-static bool refill4_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); return !(n && atoi(n) == 1); }
+// one-chunk-per-wave launches instead of persistent ones (tests, A/B): RT_HIP_NO_REFILL=1; RT_HIP_REFILL_SLOTS=<n> sets
+// the number of persistent waves
+static bool refill_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); return !(n && atoi(n) == 1); }
 static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
-template <class BoxT, int STACK>
-static void launch_trace_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                           unsigned long long* d_counters, hipStream_t s) {
-    const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
-    if (stats)
-        hipLaunchKernelGGL((k_trace<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-    else
-        hipLaunchKernelGGL((k_trace<BoxT, false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
+
+// n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
+template <class BoxT, int WIDTH, bool STATS, bool SHADE>
+static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+                          unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, hipStream_t s) {
+    const size_t lds = (size_t)stack_entries * TRACE_BLOCK * sizeof(uint32_t);
+    // the occupancy query is per (kernel instance, stack size); a handful of values occur
+    static unsigned cached_slots[5] = {0, 0, 0, 0, 0};
+    const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
+    if (!cached_slots[ci]) cached_slots[ci] = resident_waves(k_walk<BoxT, WIDTH, STATS, SHADE>, lds);
+    const unsigned chunks = (n_upper + 63u) / 64u;
+    // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks
+    const unsigned slots = refill_enabled() ? std::min(refill_slots(cached_slots[ci]), chunks) : chunks;
+    if (!slots) return;
+    hipLaunchKernelGGL((k_walk<BoxT, WIDTH, STATS, SHADE>), dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
 }
-// The per-lane stack needs one entry per BVH level (S.bvh_depth <= BVH_MAX_DEPTH); a smaller
-// stack means less LDS per wave, i.e. more waves per CU.
-template <class BoxT>
-static void launch_trace_t(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                           unsigned long long* d_counters, hipStream_t s) {
-    if (S.bvh_depth <= 16)
-        launch_trace_s<BoxT, 16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.bvh_depth <= 24)
-        launch_trace_s<BoxT, 24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.bvh_depth <= 32)
-        launch_trace_s<BoxT, 32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else
-        launch_trace_s<BoxT, BVH_MAX_DEPTH>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
+template <class BoxT, int WIDTH>
+static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+                          bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+    // The per-lane stack needs S.stack4 entries for the BVH4 and one entry per level for the BVH2; a smaller stack means
+    // less LDS per wave, i.e. more waves per CU.
+    const uint32_t need = WIDTH == 4 ? S.stack4 : S.bvh_depth;
+    const uint32_t entries = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : need <= 48 ? 48 : 64;
+    WalkShade none;
+    memset(&none, 0, sizeof(none));
+    if (sh) {
+        if (stats) launch_walk_k<BoxT, WIDTH, true, true>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, *sh, entries, s);
+        else launch_walk_k<BoxT, WIDTH, false, true>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, *sh, entries, s);
+    } else {
+        if (stats) launch_walk_k<BoxT, WIDTH, true, false>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, none, entries, s);
+        else launch_walk_k<BoxT, WIDTH, false, false>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, none, entries, s);
+    }
 }
+static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+                            bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+    if (!n_upper) return;
+    if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
+        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s); return; }
+        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s); return; }
+    }
+    if (S.nodes16)
+        launch_walk_b<Box16, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+    else if (S.nodes32)
+        launch_walk_b<Box32, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+    else
+        launch_walk_b<Box64, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+}
+void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb, bool stats,
+                 unsigned long long* d_counters, hipStream_t s) {
+    launch_walk_any(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, nullptr, s);
+}
+void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
+                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, bool stats, unsigned long long* d_counters,
+                       hipStream_t s) {
+    WalkShade sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.pp = pp;
+    sh.depth0 = depth0;
+    sh.path_radiance = d_path_radiance;
+    launch_walk_any(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, &sh, s);
+}
+
 bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant
 
-void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueMap& qm, double t_min, double t_max,
+void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, const QueueGeom& qg, double t_min, double t_max,
                          HitBuf hb, bool stats, unsigned long long* d_counters, hipStream_t s, const PacketFuse* fuse) {
-    if (!qm.n_waves) return;
-    const dim3 grid(qm.n_waves), block(TRACE_BLOCK);
+    if (!qg.n_direct) return;
+    const dim3 grid((qg.n_direct + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
     PassParams pp;
     if (gen) pp = *gen; else memset(&pp, 0, sizeof(pp));
     PacketFuse f;
     if (fuse && gen) f = *fuse; else memset(&f, 0, sizeof(f));
     // (a BVH4 variant of this kernel — four boxes per s_load, stack in VGPR lanes — was measured 8 % slower:
     // the wave tests all four boxes of every node on all lanes, and the node steps were not the bound)
-#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, grid, block, 0, s, S, pp, q, qm, t_min, t_max, hb, d_counters, \
-                                               f.q_out, f.out_bases, f.d_out_counts, f.d_path_radiance)
+#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, grid, block, 0, s, S, pp, q, qg, t_min, t_max, hb, d_counters, \
+                                               f.q_out, f.d_out_counts, f.d_path_radiance)
     if (fuse && gen) { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true, true>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true, true>)); }
     else if (gen)    { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, true, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, true, false>)); }
     else             { if (stats) RT_LAUNCH_PACKET((k_trace_packet<true, false, false>)); else RT_LAUNCH_PACKET((k_trace_packet<false, false, false>)); }
 #undef RT_LAUNCH_PACKET
 }
 
-template <class BoxT, int STACK>
-static void launch_trace4_s(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                            unsigned long long* d_counters, hipStream_t s) {
-    // persistent (one wave per hardware slot, lanes refilled) once the queue holds several chunks per slot
-    static const unsigned slots_plain = resident_waves(k_trace4<BoxT, false, STACK>);
-    static const unsigned slots_stats = resident_waves(k_trace4<BoxT, true, STACK>);
-    const unsigned slots = refill_slots(stats ? slots_stats : slots_plain);
-    const bool persist = refill4_enabled() && qm.n_waves >= 2u * slots;
-    const dim3 grid(persist ? slots : qm.n_waves), block(TRACE_BLOCK);
-    if (stats)
-        hipLaunchKernelGGL((k_trace4<BoxT, true, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-    else
-        hipLaunchKernelGGL((k_trace4<BoxT, false, STACK>), grid, block, 0, s, S, q, qm, t_min, t_max, hb, d_counters);
-}
-template <class BoxT>
-static void launch_trace4_t(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                            unsigned long long* d_counters, hipStream_t s) {
-    if (S.stack4 <= 16) launch_trace4_s<BoxT, 16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.stack4 <= 24) launch_trace4_s<BoxT, 24>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.stack4 <= 32) launch_trace4_s<BoxT, 32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.stack4 <= 48) launch_trace4_s<BoxT, 48>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else launch_trace4_s<BoxT, BVH4_MAX_STACK>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-}
-
-void launch_trace(const DScene& S, RayQueue q, const QueueMap& qm, double t_min, double t_max, HitBuf hb, bool stats,
-                  unsigned long long* d_counters, hipStream_t s) {
-    if (!qm.n_waves) return;
-    if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
-        if (S.nodes4) { launch_trace4_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s); return; }
-        if (S.nodes4f) { launch_trace4_t<Box32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s); return; }
-    }
-    if (S.nodes16)
-        launch_trace_t<Box16>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else if (S.nodes32)
-        launch_trace_t<Box32>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-    else
-        launch_trace_t<Box64>(S, q, qm, t_min, t_max, hb, stats, d_counters, s);
-}
-
-static void finish_map(QueueMap& m) {
-    uint32_t mx = 0;
-    for (int k = 0; k < NSHARD; ++k) mx = std::max(mx, (m.count[k] + 63u) / 64u);
-    m.n_waves = mx * NSHARD;
-    m._pad[0] = m._pad[1] = m._pad[2] = 0;
-}
-
-// The map of a queue of n entries written by k_raygen / k_prepare_rays: logical entry p belongs to
-// logical wave p / 64, which lives in shard (p / 64) % NSHARD like every other queue, so the same
-// queue_slot() addressing serves producers and consumers of all queues.
-QueueMap queue_map_single(uint32_t n) {
-    QueueMap m;
-    const uint32_t nw = (n + 63u) / 64u;                       // logical waves
-    uint32_t acc = 0;
-    for (uint32_t k = 0; k < (uint32_t)NSHARD; ++k) {
-        const uint32_t wk = nw > k ? (nw - k + NSHARD - 1) / NSHARD : 0u;   // waves of shard k
-        m.base[k] = acc;
-        // entries: all waves of the shard are full except the globally last wave
-        uint32_t cnt = wk * 64u;
-        if (wk && (nw - 1) % NSHARD == k) cnt -= nw * 64u - n;
-        m.count[k] = cnt;
-        acc += wk * 64u;
-    }
-    finish_map(m);
-    return m;
-}
-
-ShardBases shard_bases_for(const QueueMap& in) {
-    // output shard k receives the survivors of the input waves w with w % NSHARD == k
-    ShardBases b;
-    const uint32_t nw = in.n_waves;
-    uint32_t acc = 0;
-    for (uint32_t k = 0; k < (uint32_t)NSHARD; ++k) {
-        b.base[k] = acc;
-        acc += 64u * (nw > k ? (nw - k + NSHARD - 1) / NSHARD : 0u);
-    }
-    return b;
-}
-
-QueueMap queue_map_from_counts(const ShardBases& bases, const uint32_t* counts /* stride 32 */, uint32_t* total) {
-    QueueMap m;
-    uint32_t t = 0;
-    for (int k = 0; k < NSHARD; ++k) {
-        m.base[k] = bases.base[k];
-        m.count[k] = counts[32 * k];
-        t += m.count[k];
-    }
-    finish_map(m);
-    *total = t;
-    return m;
-}
-
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueMap& qm, HitBuf hb,
-                  RayQueue q_out, const ShardBases& out_bases, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s) {
-    if (!qm.n_waves) return;
-    hipLaunchKernelGGL(k_shade, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qm, hb, q_out,
-                       out_bases, d_out_counts, d_path_radiance);
+// n_upper: upper bound of the queue's entries (sizes the launch; waves beyond the queue's end leave at once)
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper, HitBuf hb,
+                  RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s) {
+    if (!n_upper) return;
+    // logical waves: NSHARD * (waves of the longest shard) for a sharded queue — a shard holds at most shard_cap entries
+    // and the whole queue at most n_upper
+    const size_t bound = qg.count ? (size_t)NSHARD * ((std::min<size_t>(qg.shard_cap, n_upper) + 63u) / 64u) : ((size_t)n_upper + 63u) / 64u;
+    hipLaunchKernelGGL(k_shade, dim3((unsigned)((bound * 64u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qg, hb, q_out,
+                       d_out_counts, d_path_radiance);
 }
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
-                       hipStream_t s) {
+                       uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s) {
     if (!pp.n_pixels || !n_local) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(pp.n_pixels)), dim3(BLOCK), 0, s, d_path_radiance, pp.n_pixels,
-                       pp.cam.width, pp.cam.height, pp.tiled, pp.group, n_local, d_rgb_sum);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(std::max<size_t>(pp.n_pixels, d_zero_counts ? n_zero : 0))), dim3(BLOCK), 0, s,
+                       d_path_radiance, pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled, pp.group, n_local, d_rgb_sum,
+                       d_zero_counts, n_zero);
 }
 void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
 }
-void launch_pack_hits(HitBuf hb, const QueueMap& qm, rt_hit* out, hipStream_t s) {
-    if (!qm.n_waves) return;
-    hipLaunchKernelGGL(k_pack_hits, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, hb, qm, out);
+void launch_pack_hits(HitBuf hb, const QueueGeom& qg, rt_hit* out, hipStream_t s) {
+    if (!qg.n_direct) return;
+    hipLaunchKernelGGL(k_pack_hits, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, hb, qg, out);
 }
-void launch_pack_rays(RayQueue q, const QueueMap& qm, rt_ray* out, hipStream_t s) {
-    if (!qm.n_waves) return;
-    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for((size_t)qm.n_waves * 64)), dim3(BLOCK), 0, s, q, qm, out);
+void launch_pack_rays(RayQueue q, const QueueGeom& qg, rt_ray* out, hipStream_t s) {
+    if (!qg.n_direct) return;
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, q, qg, out);
 }
 
 }  // namespace rt

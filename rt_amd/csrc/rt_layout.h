@@ -156,16 +156,24 @@ struct RayQueue {
 // w % NSHARD; consumer wave b reads shard b % NSHARD at offset 64*(b / NSHARD), which interleaves
 // the shards back into (roughly) the producer's order — camera tiles stay neighbours in flight, so
 // the next bounce still sweeps the scene once instead of NSHARD times.
+//
+// The geometry is FIXED per pass: shard k owns the physical slots [k * shard_cap, (k + 1) * shard_cap), with
+// shard_cap = 64 * ceil(waves of the pass / NSHARD) — the survivors of the input waves w = k (mod NSHARD) always fit.
+// The only thing that changes from bounce to bounce are the NSHARD entry counts, and they stay in DEVICE memory
+// (written by the producer's atomics, read by every consumer wave): the host never sees them, so it can queue the
+// kernels of a whole pass without waiting for any of them.
 constexpr int NSHARD = 64;
-struct QueueMap {
-    uint32_t base[NSHARD];          // first physical slot of shard k
-    uint32_t count[NSHARD];         // live entries in shard k
-    uint32_t n_waves;               // logical size in waves: NSHARD * max_k ceil(count[k] / 64)
-    uint32_t _pad[3];
+constexpr uint32_t COUNT_STRIDE = 32;            // u32 between two shard counters (128 B apart)
+struct QueueGeom {
+    const uint32_t* count;      // device: count[COUNT_STRIDE * k] = live entries of shard k; nullptr = dense queue (below)
+    uint32_t shard_cap;         // physical slots per shard (a multiple of 64)
+    uint32_t n_direct;          // count == nullptr: the queue holds entries 0 .. n_direct-1, entry p in logical wave p / 64
 };
-struct ShardBases {
-    uint32_t base[NSHARD];          // first physical slot of each OUTPUT shard
-};
+// slots per shard for a pass of n paths (host and device)
+static inline uint32_t shard_cap_for(uint64_t n) {
+    const uint64_t waves = (n + 63u) / 64u;
+    return (uint32_t)(64u * ((waves + NSHARD - 1) / NSHARD));
+}
 
 struct HitBuf {
     double* t;

@@ -27,7 +27,7 @@ def test_header_functions_are_exported_and_listed():
 
 
 def test_abi_version_and_struct_sizes():
-    assert _lib.lib().rt_abi_version() == 1
+    assert _lib.lib().rt_abi_version() == 2
     hdr = open(os.path.join(ROOT, "rt_amd", "csrc", "rt_api.hip")).read()
     for name, (dt, size) in _abi.EXPECTED_SIZES.items():
         assert dt.itemsize == size

@@ -163,14 +163,17 @@ def test_gltf_textured_mesh_to_render_vs_oracle(tmp_path, oracle):
 def test_kernel_variants_render_the_same_image(monkeypatch, textured):
     """The render path's switches change WHICH kernels run, never the result: per-lane instead of coherent-wave
     camera rays (RT_HIP_NO_PACKET), k_shade instead of fused depth-0 shading (RT_HIP_NO_FUSE), 1 / 4 / 8 passes in
-    flight (RT_HIP_PIPES).  Images and segment counts must be identical bit for bit."""
+    flight (RT_HIP_PIPES), the depth from which the persistent trace-and-shade kernel takes over (RT_HIP_TAIL_DEPTH:
+    1 = straight after the camera rays, 1000 = never), pass staggering, one-chunk-per-wave launches.  Images and
+    segment counts must be identical bit for bit."""
     desc, world, _ = textured
     cam = textured_camera(192, 108, 12, 50)
     kw = dict(spp=12, seed=17, max_paths_in_flight=192 * 108 * 2, with_stats=True)      # six passes
     base, st0 = cam.render_image(world, **kw)
     assert int(st0["passes"]) == 6
     for var, val in (("RT_HIP_NO_PACKET", "1"), ("RT_HIP_NO_FUSE", "1"), ("RT_HIP_PIPES", "1"), ("RT_HIP_PIPES", "4"),
-                     ("RT_HIP_PIPES", "8")):
+                     ("RT_HIP_PIPES", "8"), ("RT_HIP_TAIL_DEPTH", "1"), ("RT_HIP_TAIL_DEPTH", "3"), ("RT_HIP_TAIL_DEPTH", "6"),
+                     ("RT_HIP_TAIL_DEPTH", "1000"), ("RT_HIP_STAGGER", "0"), ("RT_HIP_NO_REFILL", "1")):
         monkeypatch.setenv(var, val)
         img, st = cam.render_image(world, **kw)
         monkeypatch.delenv(var)
@@ -180,7 +183,8 @@ def test_kernel_variants_render_the_same_image(monkeypatch, textured):
     ccam = scenes.cover_camera(160, 90, spp=6, max_depth=50, defocus=True)
     ckw = dict(spp=6, seed=4, max_paths_in_flight=160 * 90 * 2)
     cbase = ccam.render_image(cover, **ckw)
-    for var, val in (("RT_HIP_NO_PACKET", "1"), ("RT_HIP_NO_FUSE", "1"), ("RT_HIP_PIPES", "1")):
+    for var, val in (("RT_HIP_NO_PACKET", "1"), ("RT_HIP_NO_FUSE", "1"), ("RT_HIP_PIPES", "1"), ("RT_HIP_TAIL_DEPTH", "1"),
+                     ("RT_HIP_TAIL_DEPTH", "4")):
         monkeypatch.setenv(var, val)
         assert np.array_equal(ccam.render_image(cover, **ckw), cbase), (var, val)
         monkeypatch.delenv(var)
