@@ -109,11 +109,16 @@ def pmc_traffic(workload):
     if not files:
         return None, None, None, None
     k = json.load(open(files[-1]))["kernels"]
-    pick = lambda pre, key="traffic_bytes_per_launch": next((v.get(key) for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
-                                                             if n.startswith(pre)), None)
-    valu = {"k_trace4": pick("k_trace4<", "valu_active_per_simd_cycle"), "k_trace_packet": pick("k_trace_packet", "valu_active_per_simd_cycle"),
+    def pick(pre, key="traffic_bytes_per_launch", suf=""):
+        return next((v.get(key) for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
+                     if n.startswith(pre) and n.rstrip().endswith(suf)), None)
+
+    # stand-alone traversal = k_walk<..., SHADE = false>; the r01 summaries name it k_trace4
+    walk = lambda key: pick("k_walk<", key, "false>") if pick("k_walk<", key, "false>") is not None else pick("k_trace4<", key)
+    valu = {"k_walk": walk("valu_active_per_simd_cycle"), "k_walk_tail": pick("k_walk<", "valu_active_per_simd_cycle", "true>"),
+            "k_trace_packet": pick("k_trace_packet", "valu_active_per_simd_cycle"),
             "k_shade": pick("k_shade", "valu_active_per_simd_cycle")}
-    return (pick("k_trace4<") or pick("k_trace<")), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
+    return walk("traffic_bytes_per_launch"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
 
 
 def launch_ranks(args):
@@ -269,15 +274,13 @@ def main():
         samples_per_step = W * H * spp * world
         value = samples_per_step / (dt / args.steps) / 1e6
         rays_per_s = float(seg.item()) / dt
-        # ---- roofline of the dominant kernel (k_trace), from HIP events recorded by the library on
-        # the stream the kernel runs on, over the timed steps of rank 0
-        trace_s = sum(float(s["seconds_trace"]) for s in stats)
-        shade_s = sum(float(s["seconds_shade"]) for s in stats)
-        n_launch = sum(int(s["trace_launches"]) for s in stats)
-        seg0 = sum(int(s["ray_segments"]) for s in stats)
-        prim_s = sum(float(s["seconds_trace_primary"]) for s in stats)
-        prim_seg = sum(int(s["primary_segments"]) for s in stats)
-        bounce_rays_per_s = (seg0 - prim_seg) / max(trace_s - prim_s, 1e-12)
+        # ---- roofline of the dominant kernel: k_walk on the first-bounce queue (per-lane BVH traversal, one launch per
+        # pass), from HIP events the library records on the stream the kernel runs on, over the timed steps of rank 0
+        S = lambda key: sum(float(s_[key]) for s_ in stats)
+        bounce_s, bounce_seg, bounce_launches = S("seconds_trace_bounce"), int(S("bounce_segments")), int(S("bounce_launches"))
+        prim_s, prim_seg, n_passes = S("seconds_trace_primary"), int(S("primary_segments")), int(S("passes"))
+        tail_s, tail_seg = S("seconds_tail"), int(S("tail_segments"))
+        shade_s = S("seconds_shade")
         # Two untimed renders on THIS rank only (no collective: the other ranks are already at the final barrier):
         # visits per segment from an instrumented low-spp render of the same frame, and the kernels' durations
         # with one pass in flight (RT_HIP_PIPES=1), i.e. without other passes sharing the GPU
@@ -285,7 +288,7 @@ def main():
         img = rgb_mean.cpu().numpy()
         sst = hip_render_sum(w._h, cam, min(spp, 4), 0, 1, 2024, scratch, local_rank, True)
         torch.cuda.synchronize()
-        a_bounce_s, a_bounce_seg, a_launches = 0.0, 0, 0
+        alone = None
         if not args.no_alone:
             prev_pipes = os.environ.get("RT_HIP_PIPES")
             os.environ["RT_HIP_PIPES"] = "1"
@@ -295,30 +298,35 @@ def main():
                 del os.environ["RT_HIP_PIPES"]
             else:
                 os.environ["RT_HIP_PIPES"] = prev_pipes
-            a_bounce_s = float(ast["seconds_trace"]) - float(ast["seconds_trace_primary"])
-            a_bounce_seg = int(ast["ray_segments"]) - int(ast["primary_segments"])
-            a_launches = int(ast["trace_launches"]) - int(ast["passes"])
+            alone = ast
         prim_bytes = info["tri_bytes"] if len(desc.triangles) >= len(desc.spheres) else info["sphere_bytes"]
-        # the dominant kernel is the per-lane traversal of the bounce segments (k_trace<Box*>); camera rays go
-        # through the packet kernel (k_trace_packet, f32 boxes of 64 B per node), reported beside it
-        s_seg, s_pseg = int(sst["ray_segments"]), int(sst["primary_segments"])
-        s_nodes, s_pnodes = int(sst["nodes_visited"]), int(sst["nodes_visited_primary"])
-        s_prims, s_pprims = int(sst["prims_tested"]), int(sst["prims_tested_primary"])
-        v_n = (s_nodes - s_pnodes) / max(1, s_seg - s_pseg)
-        v_p = (s_prims - s_pprims) / max(1, s_seg - s_pseg)
+        # algorithmic bytes per segment of the dominant kernel: ray in (o, d: 48 B) + hit out (t, bu, bv, prim: 28 B) + nodes and
+        # primitives visited, counted by the instrumented kernel on the same frame (bounce launches only)
+        s_bseg = max(1, int(sst["bounce_segments"]))
+        v_n = int(sst["nodes_visited_bounce"]) / s_bseg
+        v_p = int(sst["prims_tested_bounce"]) / s_bseg
         bytes_per_seg = 48 + 28 + v_n * info["node_bytes"] + v_p * prim_bytes
-        bounce_seg, bounce_s = seg0 - prim_seg, trace_s - prim_s
-        bounce_launches = n_launch - sum(int(s["passes"]) for s in stats)
         achieved = bounce_seg * bytes_per_seg / bounce_s / 1e9 if bounce_s > 0 else 0.0
-        pv_n, pv_p = s_pnodes / max(1, s_pseg), s_pprims / max(1, s_pseg)
-        # the camera-ray kernel generates its rays and shades its own hits: per segment it writes the radiance slot of
-        # a path that ends (24 B) or the next ray of one that goes on (76 B: o, d, throughput, path id); the share
-        # that goes on is at most bounce segments / camera segments
-        a_on = min(1.0, (s_seg - s_pseg) / max(1, s_pseg))
-        p_bytes_per_seg = 24 * (1 - a_on) + 76 * a_on + pv_n * 64 + pv_p * prim_bytes
-        p_achieved = prim_seg * p_bytes_per_seg / prim_s / 1e9 if prim_s > 0 else 0.0
+        # the camera-ray kernel, per WAVE: a wave fetches each node / primitive record once for its 64 rays (scalar loads,
+        # Node32 = 64 B); per ray it writes the radiance slot of a path that ends (24 B) or the next ray of one that goes
+        # on (76 B: o, d, throughput, path id)
+        s_pseg = max(1, int(sst["primary_segments"]))
+        s_pwaves = s_pseg / 64.0
+        wv_n, wv_p = int(sst["wave_node_fetches_primary"]) / s_pwaves, int(sst["wave_prim_fetches_primary"]) / s_pwaves
+        a_on = min(1.0, (int(sst["ray_segments"]) - s_pseg - int(sst["tail_segments"])) / s_pseg)      # share of camera rays that go on
+        p_bytes_per_wave = wv_n * 64 + wv_p * prim_bytes + 64 * (24 * (1 - a_on) + 76 * a_on)
+        p_achieved = (prim_seg / 64.0) * p_bytes_per_wave / prim_s / 1e9 if prim_s > 0 else 0.0
         traffic, p_traffic, traffic_src, valu = pmc_traffic(args.workload)
-        achieved_alone = a_bounce_seg * bytes_per_seg / a_bounce_s / 1e9 if a_bounce_s > 0 else 0.0
+        roof_alone = None
+        if alone is not None:
+            a_s, a_seg = float(alone["seconds_trace_bounce"]), int(alone["bounce_segments"])
+            a_ach = a_seg * bytes_per_seg / a_s / 1e9 if a_s > 0 else 0.0
+            roof_alone = {"achieved": a_ach, "frac": a_ach / HBM_PEAK_GBS, "avg_launch_ms": a_s / max(1, int(alone["bounce_launches"])) * 1e3,
+                          "launches": int(alone["bounce_launches"]), "rays_per_s": a_seg / a_s if a_s > 0 else 0.0,
+                          "camera_kernel_rays_per_s": int(alone["primary_segments"]) / max(float(alone["seconds_trace_primary"]), 1e-12),
+                          "tail_kernel_rays_per_s": int(alone["tail_segments"]) / max(float(alone["seconds_tail"]), 1e-12),
+                          "ms_per_frame": float(alone["seconds_total"]) * 1e3}
+        k_valu = (valu or {}).get("k_walk")
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,29 +335,36 @@ def main():
             "config": {"workload": label, "width": W, "height": H, "spp_per_gpu": spp, "global_spp": spp * world,
                        "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
+            "launches_per_step": S("launches") / args.steps, "passes_per_step": n_passes / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "valu_active_per_simd_cycle": valu,        # rocprofv3 SQ_ACTIVE_INST_VALU / SIMD-cycles, same PMC summary
-                         "kernel": "k_trace4 (per-lane BVH4 traversal of bounce segments)" if info.get("bvh_width") == 4 else "k_trace (per-lane BVH2 traversal of bounce segments)",
+                         # which bound binds: the scene (BVH + triangles) is resident in L2 / Infinity Cache, measured HBM traffic is a
+                         # fraction of the algorithmic bytes, and the kernel is limited by VALU issue (rocprofv3 SQ_ACTIVE_INST_VALU per
+                         # SIMD-cycle, same committed PMC summary)
+                         "binding_bound": "valu_issue", "valu_active_per_simd_cycle": valu,
+                         "valu_roofline": {"achieved": k_valu, "peak": 1.0, "unit": "VALU-active wave-cycles per SIMD-cycle", "frac": k_valu},
+                         "kernel": "k_walk (per-lane BVH%d traversal of the first-bounce queue, one launch per pass)" % info.get("bvh_width", 4),
                          "avg_launch_ms": bounce_s / max(1, bounce_launches) * 1e3, "launches": bounce_launches,
                          "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
                          "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
-                         "rays_per_s": bounce_rays_per_s,
+                         "rays_per_s": bounce_seg / bounce_s if bounce_s > 0 else 0.0,
                          # the same kernel with one pass in flight (one extra untimed frame after the timed region)
-                         "alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBS,
-                                   "avg_launch_ms": a_bounce_s / max(1, a_launches) * 1e3, "launches": a_launches,
-                                   "rays_per_s": a_bounce_seg / a_bounce_s if a_bounce_s > 0 else 0.0},
+                         "alone": roof_alone,
                          "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak; "
                                  "several passes run on their own streams in the timed region, so its event-timed kernel durations include "
                                  "time shared with the other passes; 'alone' is the same kernel with one pass in flight" % (info["device_bytes"] / 2 ** 20)},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic, "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading)",
-                                "avg_launch_ms": prim_s / max(1, n_launch - bounce_launches) * 1e3,
-                                "launches": n_launch - bounce_launches, "segments": prim_seg,
-                                "bytes_per_segment": p_bytes_per_seg, "nodes_per_segment": pv_n, "prims_per_segment": pv_p,
+                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic,
+                                "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading); bytes counted per WAVE "
+                                          "(a wave fetches each node / primitive once for its 64 rays)",
+                                "avg_launch_ms": prim_s / max(1, n_passes) * 1e3, "launches": n_passes, "segments": prim_seg,
+                                "bytes_per_wave": p_bytes_per_wave, "node_fetches_per_wave": wv_n, "prim_fetches_per_wave": wv_p,
+                                "nodes_per_ray": int(sst["nodes_visited_primary"]) / s_pseg,
                                 "rays_per_s": prim_seg / prim_s if prim_s > 0 else 0.0},
-            "trace_fraction_of_step": trace_s / dt, "shade_fraction_of_step": shade_s / dt,
-            "trace_rays_per_s": seg0 / trace_s if trace_s > 0 else 0.0,
+            "tail_kernel": {"kernel": "k_walk<SHADE> (persistent trace + shade of every bounce from depth 2 on, one launch per pass)",
+                            "segments": tail_seg, "avg_launch_ms": tail_s / max(1, n_passes) * 1e3,
+                            "rays_per_s": tail_seg / tail_s if tail_s > 0 else 0.0},
+            "trace_fraction_of_step": (prim_s + bounce_s) / dt, "shade_fraction_of_step": shade_s / dt, "tail_fraction_of_step": tail_s / dt,
             "scene": {"bvh_nodes": info["n_nodes"], "bvh_depth": info["bvh_depth"], "device_mb": info["device_bytes"] / 2 ** 20,
                       "bvh_build_s": info["build_seconds"], "upload_s": info["upload_seconds"], "create_s": create_s},
             "image_mean": float(img.mean()),

@@ -227,6 +227,34 @@ int rt_render_accumulate_device(const rt_scene* scene, const rt_camera* cam, con
 int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_values,
                       uint64_t total_spp, int device, void* stream);
 
+/* Single-process multi-GPU form of rt_render (BASELINE north_star: sample-index partition + RCCL sum-reduce over xGMI):
+ * scenes[g] is the SAME scene created on device g's GPU (rt_scene_create once per device; n_devices distinct devices).
+ * One host thread per device renders the frame's samples g, g + N, g + 2N, ... of opts->spp (opts->sample_offset /
+ * sample_stride are applied first; opts->device is ignored) into a device buffer of per-pixel sums; the buffers are
+ * summed into scenes[0]'s device with ncclReduce (f64, W*H*3 values; librccl.so.1 is loaded on first use), divided by
+ * opts->spp there and copied to out_rgb_mean.  The union of the samples is that of rt_render with the same opts, so
+ * the image differs only by the order of the cross-device additions (bit-identical for n_devices == 1).
+ * stats: NULL or n_devices entries, one per device.  Extends `.sum::<Vec3>()` of src/camera.rs:316-324 across GPUs. */
+int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,
+                    double* out_rgb_mean, rt_stats* stats);
+
+/* One sweep of the progressive preview loop (window::render_thread, src/window.rs:256-311): every pixel gets
+ * render_pixel(x, y, n_samples) — Halton points 0 .. n_samples-1 again, fresh scatter randomness through `seed` —
+ * and the result is blended into the frame the scene keeps ON THE DEVICE:
+ *     new * (n_samples / total_samples) + old * (1 - n_samples / total_samples)            (:292-295)
+ * total_samples counts this sweep (the reference's num_samples_total[i]); total_samples == n_samples starts a new
+ * progression.  With RT_PASS_QUANTISE `old` is the 8-bit linear frame / 255 and the result is re-quantised with
+ * as_rgb_linear, exactly the reference's accumulation (:279-310); without it `old` is a float frame kept beside it.
+ * out_rgba8 (may be NULL): W*H*4 bytes, linear RGB + 0xff, the `pixels` frame of the window.  out_rgb_mean (may be
+ * NULL): W*H*3 doubles, the float frame.  Frame buffers belong to the scene: no allocation per sweep. */
+#define RT_PASS_QUANTISE 1u
+int rt_render_pass(const rt_scene* scene, const rt_camera* cam, uint32_t n_samples, uint64_t total_samples,
+                   uint64_t seed, uint32_t flags, uint8_t* out_rgba8, double* out_rgb_mean, rt_stats* stats);
+
+/* The output stage on the device: Vec3Ext::as_rgb_gamma (src/vec3.rs:71-97) over a resolved frame in device memory
+ * (e.g. rt_resolve_device's output), queued on `stream`; clamps like rt_encode_gamma8. */
+int rt_encode_gamma8_device(const double* d_rgb_mean, size_t n_values, uint8_t* d_out, int device, void* stream);
+
 /* Vec3Ext::as_rgb_gamma (src/vec3.rs:71-97) over an image on the host: round(pow(c,1/2.2)*255);
  * values outside [0,1] are clamped instead of panicking (documented deviation). */
 int rt_encode_gamma8(const double* rgb_mean, size_t n_values, uint8_t* out);

@@ -42,6 +42,9 @@ def lib():
     L.rt_render_accumulate_device.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rt_resolve_device.argtypes = [vp, vp, sz, u64, i32, vp]
     L.rt_encode_gamma8.argtypes = [vp, sz, vp]
+    L.rt_encode_gamma8_device.argtypes = [vp, sz, vp, i32, vp]
+    L.rt_render_pass.argtypes = [vp, vp, u32, u64, u64, u32, vp, vp, vp]
+    L.rt_render_multi.argtypes = [vp, u32, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("rt_abi_version", "rt_last_error", "rt_scene_destroy"):
             getattr(L, name).restype = C.c_int
@@ -53,7 +56,8 @@ def lib():
 EXPORTS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_get_info", "rt_trace_closest", "rt_trace_closest_noalloc", "rt_trace_primary", "rt_render",
-    "rt_render_accumulate_device", "rt_resolve_device", "rt_encode_gamma8",
+    "rt_render_accumulate_device", "rt_resolve_device", "rt_encode_gamma8", "rt_encode_gamma8_device",
+    "rt_render_pass", "rt_render_multi",
 ]
 
 

@@ -447,6 +447,27 @@ class Camera:
         check(lib().rt_render(world._h, _abi.ptr(self.rec), _abi.ptr(o), _abi.ptr(out), _abi.ptr(st)))
         return (out, st[0]) if with_stats else out
 
+    def render_image_multi(self, worlds, spp=None, seed=0, with_stats=False, **kw):
+        """Camera::render_image on several GPUs of this process: worlds[g] is the same scene built on device g
+        (World.build(desc, device=g)); rt_render_multi partitions the samples by index and sum-reduces over RCCL."""
+        o = self.opts(spp=spp, seed=seed, device=worlds[0].device, **kw)
+        out = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        st = np.zeros(len(worlds), _abi.stats_dt)
+        handles = (C.c_void_p * len(worlds))(*[w._h for w in worlds])
+        check(lib().rt_render_multi(handles, len(worlds), _abi.ptr(self.rec), _abi.ptr(o), _abi.ptr(out), _abi.ptr(st)))
+        return (out, st) if with_stats else out
+
+    def render_pass(self, world, n_samples, total_samples, seed=0, quantise=True, with_mean=False, with_stats=False):
+        """One sweep of window::render_thread (src/window.rs:256-311) through rt_render_pass: the scene keeps the
+        frame on the device; returns the (H, W, 4) uint8 linear RGBA frame (and the float frame, and stats)."""
+        rgba = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        mean = np.zeros((self.height, self.width, 3), dtype=np.float64) if with_mean else None
+        st = _abi.one(_abi.stats_dt)
+        check(lib().rt_render_pass(world._h, _abi.ptr(self.rec), int(n_samples), int(total_samples), int(seed),
+                                   1 if quantise else 0, _abi.ptr(rgba), _abi.ptr(mean), _abi.ptr(st)))
+        out = (rgba,) + ((mean,) if with_mean else ()) + ((st[0],) if with_stats else ())
+        return out[0] if len(out) == 1 else out
+
     def render_pixel(self, world, x, y, num_samples, seed=0):
         """Camera::render_pixel(world, x, y, n): served from a 1-pixel window of the same kernels
         (the camera record is shifted so that pixel (0,0) is (x,y); RNG keys use the real pixel

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <new>
 #include <string>
@@ -136,6 +137,8 @@ struct Workspace {
     HitBuf hb;
     double* path_radiance = nullptr;
     uint32_t* counters = nullptr;                  // 2 sets of NSHARD queue counters, 128 B apart (device only: no host copy exists)
+    uint32_t* hist = nullptr;                      // HIST_DEPTHS u32 right behind them: queue sizes the kernels report per pass
+    uint32_t* h_hist = nullptr;                    // pinned copy, read when the pipe is reused (launch estimates only)
     unsigned long long* stat_counters = nullptr;   // STAT_GROUPS groups of STAT_GROUP u64
     unsigned long long* h_stat = nullptr;          // pinned copy of them
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the pass in flight
@@ -152,13 +155,19 @@ struct rt_scene {
     bool device_built = false;       // BVH from bvh_gpu.hip
     Workspace ws[MAX_PIPES];         // one per in-flight pass (DEFAULT_PIPES passes are pipelined by default)
     hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {};
+    hipStream_t hi_stream[MAX_PIPES] = {};       // high-priority side stream of each pipe (the short phases of a pass)
+    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {}, ev_bulk[MAX_PIPES] = {};
     // progressive preview state (rt_render_pass): per-pass sums, the running float frame and the 8-bit linear frame
     double* pv_sum = nullptr;
     double* pv_mean = nullptr;
     uint8_t* pv_rgba8 = nullptr;
     size_t pv_pixels = 0;
     uint64_t pv_total = 0;
+    // share of a pass's paths that is still alive at depth d, as the last passes reported it (0 = not known yet): sizes
+    // the shading launches and nothing else
+    double alive_ratio[HIST_DEPTHS] = {};
+    // depth from which the persistent trace-and-shade kernel takes over; follows the reported queue sizes (render_into)
+    uint32_t tail_depth = 4;
 };
 
 namespace {
@@ -166,22 +175,27 @@ namespace {
 void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
     if (w.h_stat) (void)hipHostFree(w.h_stat);
+    if (w.h_hist) (void)hipHostFree(w.h_hist);
     for (auto& e : w.ev)
         if (e) (void)hipEventDestroy(e);
     w = Workspace();
 }
 
+constexpr size_t HIST_BYTES = 256;                 // >= HIST_DEPTHS * 4, keeps the alignment of what follows
+
 size_t workspace_bytes(size_t paths) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t slots = paths + QUEUE_SLACK;     // sharded queues pad every shard to a multiple of 64
     const size_t dsz = up(slots * sizeof(double)), usz = up(slots * sizeof(uint32_t));
-    return 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 2 * COUNTER_BYTES + STAT_BYTES;
+    return 2 * (9 * dsz + usz) + (3 * dsz + usz) + up(3 * paths * sizeof(double)) + 2 * COUNTER_BYTES + HIST_BYTES + STAT_BYTES;
 }
 
 int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
     Workspace& w = sc->ws[which];
     if (!w.h_stat) {
         HIPCHK(hipHostMalloc((void**)&w.h_stat, STAT_BYTES, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&w.h_hist, HIST_BYTES, hipHostMallocDefault));
+        memset(w.h_hist, 0, HIST_BYTES);
         for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
     }
     if (paths <= w.capacity) return RT_OK;
@@ -216,6 +230,7 @@ int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
     w.hb.prim = (uint32_t*)take(usz);
     w.path_radiance = (double*)take(up(3 * paths * sizeof(double)));
     w.counters = (uint32_t*)take(2 * COUNTER_BYTES);
+    w.hist = (uint32_t*)take(HIST_BYTES);
     w.stat_counters = (unsigned long long*)take(STAT_BYTES);
     w.capacity = paths;
     return RT_OK;
@@ -280,6 +295,9 @@ int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
+
+int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
+                         rt_stats* stats, uint32_t per_pass, uint32_t n_passes, int n_pipes, const PassParams& pp0, uint32_t group_cap);
 
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
 //
@@ -352,6 +370,22 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : sc->ev_cam) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : sc->ev_bulk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // The short phases of a pass (shading, the tail kernel, the sums) run on a high-priority stream of their own: next to
+    // the persistent traversal waves and the camera-ray kernels of the other passes their small workgroups would otherwise
+    // wait for slots for ten times their own duration, and the pass with them.  RT_HIP_PRIO=0: everything on one stream.
+    // (More than four hardware queues per process stall for SECONDS on this platform — queues are time-sliced then —, so
+    // the side streams count against the passes in flight: mode 1 = one per pipe, at most two pipes; mode 2 = one side
+    // stream shared by all pipes, at most three pipes.)
+    const int prio_mode = env_int("RT_HIP_PRIO", 0);
+    const bool use_prio = prio_mode != 0;
+    if (use_prio) {
+        n_pipes = std::min(n_pipes, prio_mode == 1 ? 2 : 3);
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int k = 0; k < (prio_mode == 1 ? n_pipes : 1); ++k)
+            if (!sc->hi_stream[k]) HIPCHK(hipStreamCreateWithPriority(&sc->hi_stream[k], hipStreamNonBlocking, greatest));
     }
     for (int k = 1; k < n_pipes; ++k)
         if (!sc->aux_stream[k]) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
@@ -371,22 +405,38 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const int ge = env_int("RT_HIP_GROUP", 0);
     const uint32_t group_cap = ge > 0 ? (uint32_t)ge : 16u;
 
+    if (env_int("RT_HIP_HOST_LOOP", 0) && !opts->collect_stats)
+        return render_into_hostloop(sc, cam, opts, d_rgb_sum, stream, stats, per_pass, n_passes, n_pipes, pp0, group_cap);
+
     rt_stats st;
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
     const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
     const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");      // depth-0 shading inside the camera-ray kernel
-    const uint32_t tail_depth = (uint32_t)std::max(1, env_int("RT_HIP_TAIL_DEPTH", 2));
-    const bool stagger = env_int("RT_HIP_STAGGER", 1) != 0;               // a pass starts when the one before it has traced its camera rays
+    // Depth from which the persistent trace-and-shade kernel takes over.  Stand-alone k_walk + k_shade launches are the
+    // efficient way through a queue of any size (full occupancy, half the registers), the persistent kernel is the way
+    // through the few thousand paths that are left after some bounces (one launch, no matter how deep they go): the
+    // switch follows the sizes the passes report — one depth later while the persistent kernel still receives more than
+    // TAIL_MAX_PATHS paths, one earlier when the last stand-alone pair saw fewer than a quarter of that.
+    // RT_HIP_TAIL_DEPTH=<d> fixes it (tests, A/B).  The image does not depend on it.
+    constexpr uint32_t TAIL_MAX_PATHS = 1u << 15;
+    const int td_env = env_int("RT_HIP_TAIL_DEPTH", 0);
+    auto tail_depth_now = [&]() -> uint32_t { return td_env > 0 ? (uint32_t)td_env : sc->tail_depth; };
+    const int stagger_mode = env_int("RT_HIP_STAGGER", 1);
+    const bool stagger = stagger_mode != 0;
 
     struct Pipe {
         Workspace* w = nullptr;
-        hipStream_t s = nullptr;
+        hipStream_t s = nullptr;      // bulk phases: camera rays, first-bounce traversal
+        hipStream_t h = nullptr;      // short phases (== s without priorities)
         bool in_flight = false;
+        uint32_t n = 0;               // paths of the pass in flight
+        uint32_t tail_depth = 0;      // and the switch depth it ran with
     } pipes[MAX_PIPES];
     for (int k = 0; k < n_pipes; ++k) {
         pipes[k].w = &sc->ws[k];
         pipes[k].s = k ? sc->aux_stream[k] : stream;
+        pipes[k].h = use_prio ? sc->hi_stream[prio_mode == 1 ? k : 0] : pipes[k].s;
     }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
@@ -394,7 +444,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     }
     for (int k = 0; k < n_pipes; ++k) {
         // queue counters start at zero (every pass leaves them cleared again: k_accumulate), statistics too
-        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES, pipes[k].s));
+        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
         HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
     }
     const double t0 = now_s();
@@ -411,8 +461,19 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         st.seconds_trace += (ms[0] + ms[1]) * 1e-3;
         st.seconds_shade += (ms[2] + ms[4]) * 1e-3;
         st.seconds_tail += ms[3] * 1e-3;
+        for (int d = 1; d < HIST_DEPTHS; ++d)          // what this pass reported: the next launches are sized by it
+            if (w.h_hist[d] && P.n) sc->alive_ratio[d] = (double)w.h_hist[d] / (double)P.n;
+        const uint32_t td = P.tail_depth;
+        if (td_env <= 0 && td == sc->tail_depth && td < (uint32_t)HIST_DEPTHS) {
+            if (w.h_hist[td] > TAIL_MAX_PATHS && td + 1 < (uint32_t)HIST_DEPTHS) sc->tail_depth = td + 1;
+            else if (td > 2 && w.h_hist[td - 1] < TAIL_MAX_PATHS / 4) sc->tail_depth = td - 1;
+        }
         P.in_flight = false;
         return RT_OK;
+    };
+    auto estimate = [&](uint32_t depth, uint32_t n) -> uint32_t {
+        if (depth >= (uint32_t)HIST_DEPTHS || !(sc->alive_ratio[depth] > 0.0) || getenv("RT_HIP_NO_ESTIMATE")) return 0u;
+        return (uint32_t)std::min<double>((double)n, sc->alive_ratio[depth] * (double)n + 1.0);
     };
 
     int prev_pipe = -1;
@@ -435,8 +496,12 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         unsigned long long* sg_bounce = w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE;
         unsigned long long* sg_tail = w.stat_counters + STAT_GROUP * STAT_GROUP_TAIL;
 
-        // the coherent camera rays of this pass share the GPU with the incoherent bounces of the pass before it
-        if (stagger && prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
+        // Ramp: the first pass of every pipe starts when the pass before it has traced its camera rays, so that the pipes
+        // run out of phase (the coherent camera rays of one pass share the GPU with the incoherent bounces of another);
+        // after that every pipe runs free.  RT_HIP_STAGGER=0: no ramp, =2: every pass waits (strict camera chain).
+        if (stagger && prev_pipe >= 0 && prev_pipe != k && (pass < (uint32_t)n_pipes || stagger_mode == 2))
+            HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
+        if (use_prio && pass >= (uint32_t)n_pipes) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[k], 0));     // the pipe's last pass has left the workspace
         HIPCHK(hipEventRecord(w.ev[0], P.s));
         // ---- depth 0: survivors -> q[1], counts cnt[0]
         if (use_packet) {
@@ -449,7 +514,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.launches += 2;
         }
         if (!fuse_shade) {
-            launch_shade(sc->d, pp, 0u, w.q[0], dense, n, w.hb, w.q[1], cnt[0], w.path_radiance, P.s);
+            launch_shade(sc->d, pp, 0u, w.q[0], dense, n, 0u, w.hb, w.q[1], cnt[0], w.path_radiance, nullptr, P.s);
             st.launches++;
         }
         st.trace_launches++;
@@ -459,43 +524,61 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         int cur = 1, cset = 0;
         uint32_t depth = 1;
         bool ev2 = false;
+        hipStream_t ws = P.s;                 // the stream the pass is on: it moves to the side stream after the first-bounce traversal
+        auto to_side = [&]() -> int {
+            if (ws == P.h) return RT_OK;
+            HIPCHK(hipEventRecord(sc->ev_bulk[k], P.s));
+            HIPCHK(hipStreamWaitEvent(P.h, sc->ev_bulk[k], 0));
+            ws = P.h;
+            return RT_OK;
+        };
+        const uint32_t tail_depth = tail_depth_now();
         for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_bounce, P.s);
+            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_bounce, ws, estimate(depth, n));
             st.trace_launches++;
             st.bounce_launches++;
-            if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], P.s)); ev2 = true; }
-            if (depth >= 2) HIPCHK(hipMemsetAsync(cnt[cset ^ 1], 0, COUNTER_BYTES, P.s));      // (set last read two kernels ago)
-            launch_shade(sc->d, pp, depth, w.q[cur], qg, n, w.hb, w.q[cur ^ 1], cnt[cset ^ 1], w.path_radiance, P.s);
-            st.launches += 2;
+            if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], ws)); ev2 = true; }
+            if ((rc = to_side())) return rc;
+            if (depth >= 2) HIPCHK(hipMemsetAsync(cnt[cset ^ 1], 0, COUNTER_BYTES, ws));      // (set last read two kernels ago)
+            const uint32_t est = estimate(depth, n);
+            launch_shade(sc->d, pp, depth, w.q[cur], qg, n, est, w.hb, w.q[cur ^ 1], cnt[cset ^ 1], w.path_radiance,
+                         depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, ws);
+            st.launches += est && est < n ? 3 : 2;
             cur ^= 1;
             cset ^= 1;
         }
-        if (!ev2) HIPCHK(hipEventRecord(w.ev[2], P.s));
-        HIPCHK(hipEventRecord(w.ev[3], P.s));
+        if (!ev2) HIPCHK(hipEventRecord(w.ev[2], ws));
+        if ((rc = to_side())) return rc;
+        HIPCHK(hipEventRecord(w.ev[3], ws));
         // ---- every remaining bounce inside one persistent launch
         if (depth <= cam->max_depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk_shade(sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance, want_stats, sg_tail, P.s);
+            launch_walk_shade(sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance,
+                              depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, want_stats, sg_tail, ws, estimate(depth, n));
             st.launches++;
         }
-        HIPCHK(hipEventRecord(w.ev[4], P.s));
+        HIPCHK(hipMemcpyAsync(w.h_hist, w.hist, HIST_DEPTHS * sizeof(uint32_t), hipMemcpyDeviceToHost, ws));
+        HIPCHK(hipEventRecord(w.ev[4], ws));
         // ---- radiance sums are added pass by pass in pass order (bit-reproducible), whichever pipe is first
-        if (prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[prev_pipe], 0));
-        launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, w.counters, (uint32_t)(2 * COUNTER_BYTES / 4), P.s);
-        HIPCHK(hipEventRecord(sc->ev_acc[k], P.s));
-        HIPCHK(hipEventRecord(w.ev[5], P.s));
+        if (prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(ws, sc->ev_acc[prev_pipe], 0));
+        launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, w.counters, (uint32_t)((2 * COUNTER_BYTES + HIST_BYTES) / 4), ws);
+        HIPCHK(hipEventRecord(sc->ev_acc[k], ws));
+        HIPCHK(hipEventRecord(w.ev[5], ws));
         HIPCHK(hipGetLastError());
         st.launches++;
         st.passes++;
         st.samples += (uint64_t)n;
         st.primary_segments += n;
         P.in_flight = true;
+        P.n = n;
+        P.tail_depth = tail_depth;
         prev_pipe = k;
     }
     int first_err = RT_OK;
     for (int k = 0; k < n_pipes; ++k) {      // drain every pipe, whatever happened on another one
-        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s);
+        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].h);
+        if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].h);
         if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].s);
         if (e != hipSuccess && !first_err) {
             (void)hipGetLastError();
@@ -538,6 +621,167 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             }
         }
     }
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+
+// EXPERIMENT / A-B (RT_HIP_HOST_LOOP=1): the round-1 schedule on the same kernels — the host reads the queue counts after every
+// bounce (pinned copy + event, polled), sizes every launch exactly and runs stand-alone k_walk + k_shade pairs until no
+// path is left.  One host round trip per bounce and pipe; kept to measure what the device-driven schedule gains or loses.
+int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
+                         rt_stats* stats, uint32_t per_pass, uint32_t n_passes, int n_pipes, const PassParams& pp0, uint32_t group_cap) {
+    const size_t npix = (size_t)cam->width * cam->height;
+    rt_stats st;
+    memset(&st, 0, sizeof(st));
+    const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
+    const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");
+    static uint32_t* h_counts[MAX_PIPES] = {};
+    static hipEvent_t ev_b[MAX_PIPES] = {};
+    for (int k = 0; k < n_pipes; ++k)
+        if (!h_counts[k]) {
+            HIPCHK(hipHostMalloc((void**)&h_counts[k], COUNTER_BYTES, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ev_b[k], hipEventDisableTiming));
+        }
+    struct Pipe {
+        Workspace* w = nullptr;
+        hipStream_t s = nullptr;
+        PassParams pp;
+        uint32_t pass = 0, nl = 0, n = 0, depth = 0, scap = 0, n_waves = 0;
+        int cur = 0, cset = 0;
+        enum { IDLE, RUNNING, WAIT_ACC } state = IDLE;
+    } pipes[MAX_PIPES];
+    for (int k = 0; k < n_pipes; ++k) {
+        pipes[k].w = &sc->ws[k];
+        pipes[k].s = k ? sc->aux_stream[k] : stream;
+    }
+    if (n_pipes > 1) {
+        HIPCHK(hipEventRecord(sc->ev_fork, stream));
+        for (int k = 1; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
+    }
+    for (int k = 0; k < n_pipes; ++k) {
+        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
+        HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
+    }
+    uint32_t next_pass = 0, next_acc = 0, done_passes = 0;
+    int last_acc_pipe = -1, rc;
+    const double t0 = now_s();
+    auto cnt_of = [&](Pipe& P, int set) { return P.w->counters + (COUNTER_BYTES / 4) * set; };
+    auto readback = [&](Pipe& P, int k) -> int {      // counts of the queue the last shade produced
+        HIPCHK(hipMemcpyAsync(h_counts[k], cnt_of(P, P.cset), COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
+        HIPCHK(hipEventRecord(ev_b[k], P.s));
+        return RT_OK;
+    };
+    auto start_pass = [&](Pipe& P, int k) -> int {
+        Workspace& w = *P.w;
+        P.pass = next_pass++;
+        const uint32_t base = P.pass * per_pass;
+        P.nl = std::min(per_pass, opts->spp - base);
+        P.n = (uint32_t)(npix * P.nl);
+        P.pp = pp0;
+        P.pp.pass_base = base;
+        for (uint32_t g = 64; g > 1; g >>= 2)
+            if (g <= group_cap && P.nl % g == 0 && npix % (64u / g) == 0) { P.pp.group = g; break; }
+        P.scap = shard_cap_for(P.n);
+        const QueueGeom dense = {nullptr, P.scap, P.n};
+        HIPCHK(hipMemsetAsync(w.counters, 0, 2 * COUNTER_BYTES, P.s));
+        if (use_packet) {
+            PacketFuse f = {w.q[1], cnt_of(P, 0), w.path_radiance};
+            launch_trace_packet(sc->d, &P.pp, w.q[0], dense, cam->t_min, cam->t_max, w.hb, false, nullptr, P.s, fuse_shade ? &f : nullptr);
+        } else {
+            launch_raygen(P.pp, dense, w.q[0], P.s);
+            launch_walk(sc->d, w.q[0], dense, P.n, cam->t_min, cam->t_max, w.hb, false, nullptr, P.s);
+        }
+        if (!fuse_shade) launch_shade(sc->d, P.pp, 0u, w.q[0], dense, P.n, 0u, w.hb, w.q[1], cnt_of(P, 0), w.path_radiance, nullptr, P.s);
+        st.launches += 2;
+        st.primary_segments += P.n;
+        P.cur = 1; P.cset = 0; P.depth = 0;
+        P.state = Pipe::RUNNING;
+        return readback(P, k);
+    };
+    auto bounce = [&](Pipe& P, int k) -> int {       // queue q[cur] / counts cset, P.n entries in P.n_waves logical waves
+        Workspace& w = *P.w;
+        const QueueGeom qg = {cnt_of(P, P.cset), P.scap, 0u};
+        launch_walk(sc->d, w.q[P.cur], qg, P.n_waves * 64u, cam->t_min, cam->t_max, w.hb, false,
+                    w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE, P.s);
+        HIPCHK(hipMemsetAsync(cnt_of(P, P.cset ^ 1), 0, COUNTER_BYTES, P.s));
+        launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], qg, P.n, 0u, w.hb, w.q[P.cur ^ 1], cnt_of(P, P.cset ^ 1), w.path_radiance, nullptr,
+                     P.s, P.n_waves);
+        st.launches += 2;
+        st.trace_launches++;
+        P.cur ^= 1; P.cset ^= 1;
+        return readback(P, k);
+    };
+    auto accumulate = [&](Pipe& P, int k) -> int {
+        if (last_acc_pipe >= 0 && last_acc_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[last_acc_pipe], 0));
+        launch_accumulate(P.pp, P.w->path_radiance, P.nl, d_rgb_sum, nullptr, 0u, P.s);
+        HIPCHK(hipEventRecord(sc->ev_acc[k], P.s));
+        last_acc_pipe = k;
+        ++next_acc; ++done_passes;
+        st.launches++; st.passes++;
+        st.samples += (uint64_t)npix * P.nl;
+        P.state = Pipe::IDLE;
+        return RT_OK;
+    };
+    if ((rc = start_pass(pipes[0], 0))) return rc;
+    int started = 1;
+    while (done_passes < n_passes) {
+        bool progressed = false;
+        for (int k = 0; k < n_pipes; ++k) {
+            Pipe& P = pipes[k];
+            if (P.state == Pipe::IDLE) {
+                if (next_pass < n_passes && k < started) {
+                    if ((rc = start_pass(P, k))) return rc;
+                    progressed = true;
+                }
+                continue;
+            }
+            if (P.state == Pipe::WAIT_ACC) {
+                if (P.pass == next_acc) {
+                    if ((rc = accumulate(P, k))) return rc;
+                    progressed = true;
+                }
+                continue;
+            }
+            const hipError_t qe = hipEventQuery(ev_b[k]);
+            if (qe == hipErrorNotReady) continue;
+            if (qe != hipSuccess) HIPCHK(qe);
+            progressed = true;
+            uint32_t tot = 0, mx = 0;
+            for (int sh = 0; sh < NSHARD; ++sh) {
+                const uint32_t c = h_counts[k][COUNT_STRIDE * sh];
+                tot += c;
+                mx = std::max(mx, (c + 63u) / 64u);
+            }
+            P.n = tot;
+            P.n_waves = mx * NSHARD;
+            P.depth++;
+            if (k == started - 1 && started < n_pipes) {
+                ++started;
+                if (next_pass < n_passes && (rc = start_pass(pipes[started - 1], started - 1))) return rc;
+            }
+            if (P.n == 0 || P.depth > cam->max_depth) {
+                P.state = Pipe::WAIT_ACC;
+                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
+            } else if ((rc = bounce(P, k))) {
+                return rc;
+            }
+        }
+        if (!progressed) std::this_thread::yield();
+    }
+    for (int k = 0; k < n_pipes; ++k) {
+        HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s));
+        HIPCHK(hipStreamSynchronize(pipes[k].s));
+    }
+    HIPCHK(hipGetLastError());
+    st.seconds_total = now_s() - t0;
+    st.ray_segments = st.primary_segments;
+    for (int k = 0; k < n_pipes; ++k) {
+        const unsigned long long* hb_ = pipes[k].w->h_stat + STAT_GROUP * STAT_GROUP_BOUNCE;
+        st.bounce_segments += hb_[STAT_SEGMENTS];
+        st.ray_segments += hb_[STAT_SEGMENTS];
+    }
+    st.seconds_trace_bounce = st.seconds_trace_primary = st.seconds_trace = 1e-9;
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -824,6 +1068,10 @@ void rt_scene_destroy(rt_scene* sc) {
         for (auto& w : sc->ws) free_workspace(w);
         for (auto& a : sc->aux_stream)
             if (a) (void)hipStreamDestroy(a);
+        for (auto& a : sc->hi_stream)
+            if (a) (void)hipStreamDestroy(a);
+        for (auto& e : sc->ev_bulk)
+            if (e) (void)hipEventDestroy(e);
         if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
         for (auto& e : sc->ev_acc)
             if (e) (void)hipEventDestroy(e);
@@ -1041,6 +1289,216 @@ int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, do
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipGetLastError());
     return RT_OK;
+}
+
+int rt_encode_gamma8_device(const double* d_rgb_mean, size_t n_values, uint8_t* d_out, int device, void* stream) {
+    if (n_values && (!d_rgb_mean || !d_out)) return fail(RT_ERR_INVALID, "NULL argument");
+    DeviceGuard dg;
+    int rc = select_device(device);
+    if (rc) return rc;
+    launch_gamma8(d_rgb_mean, n_values, d_out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_pass(const rt_scene* csc, const rt_camera* cam, uint32_t n_samples, uint64_t total_samples, uint64_t seed,
+                   uint32_t flags, uint8_t* out_rgba8, double* out_rgb_mean, rt_stats* stats) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (!n_samples || total_samples < n_samples) return fail(RT_ERR_INVALID, "need 1 <= n_samples <= total_samples");
+    if (flags & ~(uint32_t)RT_PASS_QUANTISE) return fail(RT_ERR_INVALID, "unknown flag bits 0x%x", flags);
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
+    if ((rc = select_device(sc->device))) return rc;
+    const size_t npix = (size_t)cam->width * cam->height;
+    const bool first = total_samples == n_samples;               // sweep 1: the old frame has weight 0 (src/window.rs:293-295)
+    if (sc->pv_pixels != npix) {                                 // frame buffers live with the scene: no allocation per pass
+        if (!first) return fail(RT_ERR_INVALID, "rt_render_pass: frame size changed in the middle of a progression (start with total_samples == n_samples)");
+        if (sc->pv_sum) (void)hipFree(sc->pv_sum);
+        if (sc->pv_mean) (void)hipFree(sc->pv_mean);
+        if (sc->pv_rgba8) (void)hipFree(sc->pv_rgba8);
+        sc->pv_sum = sc->pv_mean = nullptr; sc->pv_rgba8 = nullptr; sc->pv_pixels = 0;
+        HIPCHK(hipMalloc((void**)&sc->pv_sum, npix * 3 * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&sc->pv_mean, npix * 3 * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&sc->pv_rgba8, npix * 4));
+        sc->pv_pixels = npix;
+    }
+    hipStream_t stream = nullptr;
+    if (first) {
+        HIPCHK(hipMemsetAsync(sc->pv_mean, 0, npix * 3 * sizeof(double), stream));
+        HIPCHK(hipMemsetAsync(sc->pv_rgba8, 0, npix * 4, stream));
+    } else if (total_samples - n_samples != sc->pv_total) {
+        return fail(RT_ERR_INVALID, "rt_render_pass: total_samples - n_samples = %llu but the frame holds %llu samples",
+                    (unsigned long long)(total_samples - n_samples), (unsigned long long)sc->pv_total);
+    }
+    HIPCHK(hipMemsetAsync(sc->pv_sum, 0, npix * 3 * sizeof(double), stream));
+    rt_opts o;
+    memset(&o, 0, sizeof(o));
+    o.spp = n_samples;                     // render_pixel(x, y, n): Halton points 0 .. n-1 again in every pass (src/window.rs:277)
+    o.sample_offset = 0;
+    o.sample_stride = 1;
+    o.precision = RT_PRECISION_F64;
+    o.seed = seed;
+    o.device = sc->device;
+    if ((rc = render_into(sc, cam, &o, sc->pv_sum, stream, stats))) return rc;
+    launch_blend_pass(sc->pv_sum, sc->pv_mean, sc->pv_rgba8, npix, n_samples, total_samples, (flags & RT_PASS_QUANTISE) != 0, stream);
+    if (out_rgba8) HIPCHK(hipMemcpyAsync(out_rgba8, sc->pv_rgba8, npix * 4, hipMemcpyDeviceToHost, stream));
+    if (out_rgb_mean) HIPCHK(hipMemcpyAsync(out_rgb_mean, sc->pv_mean, npix * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    sc->pv_total = total_samples;
+    return RT_OK;
+}
+
+// ---- single-process multi-GPU render: one host thread per device, RCCL sum-reduce over xGMI ----------------------
+namespace {
+// librccl is loaded on first use with RTLD_LOCAL: hosts that never call rt_render_multi do not depend on it, and a
+// process that already holds another copy of RCCL (torch ships its own) keeps its symbols to itself.
+struct Rccl {
+    void* h = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*Reduce)(const void* send, void* recv, size_t count, int datatype, int op, int root, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+struct CommSet { std::vector<int> devices; std::vector<void*> comms; };
+std::vector<CommSet> g_comm_sets;      // communicators are kept for the life of the process (creation takes ~a second)
+
+int rccl_load() {
+    if (g_rccl.h) return RT_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(RT_ERR_HIP, "rt_render_multi needs RCCL: dlopen(librccl.so.1) failed: %s", dlerror());
+    Rccl r;
+    r.h = h;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.Reduce = (decltype(r.Reduce))dlsym(h, "ncclReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.Reduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        dlclose(h);
+        return fail(RT_ERR_HIP, "librccl lacks an expected symbol");
+    }
+    g_rccl = r;
+    return RT_OK;
+}
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;      // ncclFloat64, ncclSum (rccl.h)
+}  // namespace
+
+int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,
+                    double* out_rgb_mean, rt_stats* stats) {
+    if (!scenes || !opts || !out_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
+    if (n_devices < 1 || n_devices > 64) return fail(RT_ERR_INVALID, "n_devices must be 1..64");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (!opts->spp) return fail(RT_ERR_INVALID, "spp must be >= 1");
+    std::vector<int> devs(n_devices);
+    for (uint32_t g = 0; g < n_devices; ++g) {
+        if (!scenes[g]) return fail(RT_ERR_INVALID, "scenes[%u] is NULL", g);
+        devs[g] = scenes[g]->device;
+        for (uint32_t j = 0; j < g; ++j)
+            if (devs[j] == devs[g]) return fail(RT_ERR_INVALID, "scenes[%u] and scenes[%u] are on the same device %d", j, g, devs[g]);
+    }
+    DeviceGuard dg;
+    // ---- communicators (one per device, created together once per device set)
+    std::vector<void*> comms;
+    {
+        std::lock_guard<std::mutex> rl(g_rccl_mu);
+        if ((rc = rccl_load())) return rc;
+        for (const CommSet& cs : g_comm_sets)
+            if (cs.devices == devs) comms = cs.comms;
+        if (comms.empty()) {
+            comms.assign(n_devices, nullptr);
+            const int r = g_rccl.CommInitAll(comms.data(), (int)n_devices, devs.data());
+            if (r != 0) return fail(RT_ERR_HIP, "ncclCommInitAll over %u devices failed: %s", n_devices, g_rccl.GetErrorString(r));
+            g_comm_sets.push_back({devs, comms});
+        }
+    }
+    const size_t nval = (size_t)cam->width * cam->height * 3;
+    const uint32_t stride0 = opts->sample_stride ? opts->sample_stride : 1;
+    // device g renders the frame's samples g, g + N, g + 2N, ... (scene replicated, sample-index partition)
+    struct PerDev { double* d_sum = nullptr; hipStream_t stream = nullptr; int rc = RT_OK; std::string err; rt_stats st{}; uint32_t spp = 0; };
+    std::vector<PerDev> pd(n_devices);
+    auto worker = [&](uint32_t g) {
+        PerDev& P = pd[g];
+        rt_scene* sc = scenes[g];
+        std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+        std::lock_guard<std::mutex> sl(sc->mu);
+        auto bail = [&](int code) { P.rc = code; P.err = g_err; };
+        if (int r = select_device(sc->device)) return bail(r);
+        if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_HIP, "hipStreamCreate failed on device %d", sc->device)); }
+        if (hipMalloc((void**)&P.d_sum, nval * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_OOM, "hipMalloc of the radiance sums failed on device %d", sc->device)); }
+        if (hipMemsetAsync(P.d_sum, 0, nval * sizeof(double), P.stream) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_HIP, "hipMemsetAsync failed")); }
+        P.spp = opts->spp > g ? (opts->spp - g + n_devices - 1) / n_devices : 0;
+        if (P.spp) {
+            rt_opts o = *opts;
+            o.spp = P.spp;
+            o.sample_offset = opts->sample_offset + g * stride0;
+            o.sample_stride = stride0 * n_devices;
+            o.device = sc->device;
+            if (int r = render_into(sc, cam, &o, P.d_sum, P.stream, &P.st)) return bail(r);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t g = 1; g < n_devices; ++g) th.emplace_back(worker, g);
+        worker(0);
+        for (auto& t : th) t.join();
+    }
+    int first_bad = -1;
+    for (uint32_t g = 0; g < n_devices; ++g)
+        if (pd[g].rc && first_bad < 0) first_bad = (int)g;
+    auto cleanup = [&]() {
+        for (uint32_t g = 0; g < n_devices; ++g) {
+            if (hipSetDevice(devs[g]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (pd[g].stream) { (void)hipStreamSynchronize(pd[g].stream); (void)hipStreamDestroy(pd[g].stream); }
+            if (pd[g].d_sum) (void)hipFree(pd[g].d_sum);
+        }
+        (void)hipGetLastError();
+    };
+    if (first_bad >= 0) {
+        cleanup();
+        g_err = "device " + std::to_string(devs[first_bad]) + ": " + pd[first_bad].err;
+        return pd[first_bad].rc;
+    }
+    // ---- the exchange step: sum the per-device buffers into device devs[0] (extends `.sum::<Vec3>()`, src/camera.rs:323)
+    {
+        std::lock_guard<std::mutex> rl(g_rccl_mu);
+        int r = g_rccl.GroupStart();
+        for (uint32_t g = 0; g < n_devices && r == 0; ++g) {
+            if (hipSetDevice(devs[g]) != hipSuccess) { (void)hipGetLastError(); r = -1; break; }
+            r = g_rccl.Reduce(pd[g].d_sum, pd[g].d_sum, nval, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], pd[g].stream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r == 0) r = r2;
+        if (r != 0) {
+            cleanup();
+            return fail(RT_ERR_HIP, "ncclReduce failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "hipSetDevice");
+        }
+    }
+    rc = select_device(devs[0]);
+    if (!rc) {
+        launch_resolve(pd[0].d_sum, pd[0].d_sum, nval, (double)opts->spp, pd[0].stream);
+        hipError_t e = hipMemcpyAsync(out_rgb_mean, pd[0].d_sum, nval * sizeof(double), hipMemcpyDeviceToHost, pd[0].stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(pd[0].stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(RT_ERR_HIP, "read-back of the reduced frame failed: %s", hipGetErrorName(e)); }
+    }
+    if (stats)
+        for (uint32_t g = 0; g < n_devices; ++g) stats[g] = pd[g].st;
+    cleanup();
+    return rc;
 }
 
 int rt_encode_gamma8(const double* rgb_mean, size_t n_values, uint8_t* out) {

@@ -143,6 +143,21 @@ struct WaveQueue {
         for (int off = 32; off; off >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, off));
         n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)w) * NSHARD;
     }
+    // One-shot waves (k_shade: a wave serves ONE logical wave) read two words through the scalar cache instead of the 64
+    // counters: the queue's size in waves, left in count[QUEUE_NWAVES_WORD] by the traversal kernel that ran over the
+    // same queue just before, and (in slot_light) their own shard's count.
+    __device__ __forceinline__ void load_light(const QueueGeom& g) {
+        shard_cap = g.shard_cap; n_direct = g.n_direct; direct = g.count == nullptr;
+        cnt = 0;
+        n_waves = direct ? (n_direct + 63u) >> 6 : g.count[QUEUE_NWAVES_WORD];
+    }
+    __device__ __forceinline__ bool slot_light(const QueueGeom& g, uint32_t wave, uint32_t lane, uint32_t& i) const {
+        const uint32_t shard = wave & (NSHARD - 1);
+        const uint32_t off = (wave / NSHARD) * 64u + lane;
+        i = shard * shard_cap + off;
+        if (direct) return wave * 64u + lane < n_direct;
+        return wave < n_waves && off < g.count[COUNT_STRIDE * shard];
+    }
     // wave: logical wave index (wave-uniform).  Returns whether this lane holds a live entry and its physical slot.
     __device__ __forceinline__ bool slot(uint32_t wave, uint32_t lane, uint32_t& i) const {
         const uint32_t shard = wave & (NSHARD - 1);

@@ -46,13 +46,14 @@ void launch_prepare_rays(const rt_ray* rays, const QueueGeom& qg, RayQueue q, hi
 // K1: closest hit for every entry of the queue -> hb.  n_upper: an upper bound of the entry count known to the host
 // (it only sizes the launch; the kernel reads the queue's counts from device memory).  d_counters: one statistics
 // group, or NULL.
+// n_estimate (0 = none): the entry count the host expects; sizes the persistent grid (any real count is still served).
 void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
-                 bool stats, unsigned long long* d_counters, hipStream_t s);
+                 bool stats, unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0);
 // K1 + K2-4, persistent: traces AND shades the queue's paths (entries at depth depth0), bounce after bounce inside
 // the kernel, until every path has ended (radiance slots written)
 void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
-                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, bool stats, unsigned long long* d_counters,
-                       hipStream_t s);
+                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
+                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0);
 // K1p: closest hit for coherent waves (camera rays; always a dense queue): wave-level packet traversal through the scalar cache
 // gen != NULL: the kernel generates the camera rays of that pass itself (K0 fused) and stores them in q
 // fuse != NULL (needs gen): the kernel also shades depth 0 and appends the survivors to fuse->q_out (the launch
@@ -68,13 +69,22 @@ void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, con
 constexpr size_t QUEUE_SLACK = 64 * NSHARD;   // physical slots beyond the path count a sharded queue may need
 constexpr size_t COUNTER_BYTES = COUNT_STRIDE * 4 * NSHARD;      // one set of shard counters
 // K2+K3+K4: shade (miss -> sky, hit -> scatter + Russian roulette) and compact survivors into q_out (same geometry)
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper, HitBuf hb,
-                  RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s);
+// n_estimate (0 = none): the entry count the host expects; it sizes the one-wave-per-wave launch, a small persistent launch
+// takes what lies beyond (correct whatever the estimate).  d_hist (may be NULL): the kernel stores the real entry count there.
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper,
+                  uint32_t n_estimate, HitBuf hb, RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, uint32_t* d_hist,
+                  hipStream_t s, uint32_t exact_waves = 0);
+constexpr int HIST_DEPTHS = 32;                // queue sizes reported per pass: entries at depth 1 .. HIST_DEPTHS-1
 // K5a: rgb_sum[pixel] += radiance of the pass's samples, in sample order; clears n_zero u32 at d_zero_counts (may be NULL)
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local_samples,
                        double* d_rgb_sum, uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s);
 // K5b: mean = sum / total_spp
 void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
+// output stage: 8-bit gamma-encoded frame from a resolved one (src/vec3.rs:71-97)
+void launch_gamma8(const double* d_mean, size_t n_values, uint8_t* d_out, hipStream_t s);
+// preview blend of one pass into the float and the 8-bit linear RGBA frame (src/window.rs:277-310)
+void launch_blend_pass(const double* d_pass_sum, double* d_mean_frame, uint8_t* d_rgba8, size_t n_pixels, uint32_t n_samples,
+                       uint64_t total_samples, bool quantise, hipStream_t s);
 // hits (SoA, dense queue) -> rt_hit[]
 void launch_pack_hits(HitBuf hb, const QueueGeom& qg, rt_hit* out, hipStream_t s);
 void launch_pack_rays(RayQueue q, const QueueGeom& qg, rt_ray* out, hipStream_t s);

@@ -271,15 +271,34 @@ struct WalkShade {
     uint32_t depth0;            // depth of the queue's entries
     uint32_t _pad;
     double* path_radiance;
+    uint32_t* hist;             // may be null
 };
 template <class BoxT, int WIDTH, bool STATS, bool SHADE>
-__global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
-                                                                       HitBuf hb, unsigned long long* counters, WalkShade sh) {
+__device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, const QueueGeom qg, double t_min, double t_max,
+                                          const HitBuf hb, unsigned long long* counters, const WalkShade sh) {
+    // (by VALUE on purpose: through references the compiler turned the base-pointer select of the fetch below into a
+    // select of ADDRESSES inside the argument block plus a per-lane load — one more dependent memory round trip per step)
     extern __shared__ uint32_t stack_mem[];
     uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
     const uint32_t tid = threadIdx.x;
+    // The queue's counts are read once here (size in waves, total) and looked up again per refill through the scalar
+    // cache (slot_light): nothing of them stays in a VGPR across the loop — the kernel's register count decides whether
+    // a camera-ray or shading wave of another pass still fits next to four of its waves on a SIMD.
     WaveQueue wq;
     wq.load(qg, tid);
+    if (blockIdx.x == 0) {
+        uint32_t tot = wq.direct ? 0u : wq.cnt;
+        for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+        if (wq.direct) tot = wq.n_direct;
+        if (tid == 0) {
+            if (SHADE && sh.hist) *sh.hist = tot;          // for the host's launch estimates
+            // for the one-shot waves of the k_shade launch that follows on the same queue
+            if (!wq.direct) const_cast<uint32_t*>(qg.count)[QUEUE_NWAVES_WORD] = wq.n_waves;
+            // stand-alone traversal: every entry is one segment (the trace-and-shade kernel counts per lane instead)
+            if (!SHADE && counters && tot) atomicAdd(&counters[STAT_SEGMENTS], (unsigned long long)tot);
+        }
+    }
+    wq.cnt = 0;
     const uint32_t n_chunks = wq.n_waves, stride = gridDim.x;
     uint32_t next_chunk = blockIdx.x, chunk = 0, chunk_pos = 64;      // wave-uniform
     bool busy = false;                                                // this lane holds a ray
@@ -319,8 +338,8 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
         }
         if (service) {
             if (busy && cur == REF_EMPTY) {                           // retire
-                ++n_seg;
                 if (SHADE) {
+                    ++n_seg;
                     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
                     const bool alive = shade_path(S, sh.pp, depth, pid, slot, o, d, thr, prim, best, hb, sh.path_radiance, no, nd, nthr);
                     if (alive) {                                      // Camera::raycast's recursion (src/camera.rs:303): the same lane goes on
@@ -346,7 +365,7 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
                 const uint32_t take = min((uint32_t)__popcll(m_idle), 64u - chunk_pos);
                 uint32_t i = 0;
-                if (!busy && rank < take && wq.slot(chunk, chunk_pos + rank, i)) {
+                if (!busy && rank < take && wq.slot_light(qg, chunk, chunk_pos + rank, i)) {
                     slot = i; busy = true;
                     o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
                     d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
@@ -482,7 +501,7 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
         RT_STAMP(tm_prim)
 #endif
     }
-    if (counters) {                                                   // (null: the allocation-free entry point keeps no counters)
+    if (SHADE && counters) {
         unsigned long long sg = n_seg;
         for (int off = 32; off; off >>= 1) sg += __shfl_xor(sg, off);
         if (tid == 0 && sg) atomicAdd(&counters[STAT_SEGMENTS], sg);
@@ -506,6 +525,26 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
 #endif
         }
     }
+}
+
+// The two kernels over walk_body: k_walk stores hits (stand-alone traversal: first bounce, rt_trace_closest, ...),
+// k_walk_shade is the persistent trace-and-shade kernel.  Separate __global__ functions so that each has its own
+// register budget: RT_TAIL_WAVES caps k_walk_shade's (its shading code wants ~200 VGPRs; held by long-lived waves they
+// would keep the other passes' kernels out of the SIMDs).
+template <class BoxT, int WIDTH, bool STATS>
+__global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
+                                                                       HitBuf hb, unsigned long long* counters, WalkShade sh) {
+    walk_body<BoxT, WIDTH, STATS, false>(S, q, qg, t_min, t_max, hb, counters, sh);
+}
+#ifdef RT_TAIL_WAVES
+#define RT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(RT_TAIL_WAVES, RT_TAIL_WAVES)))
+#else
+#define RT_TAIL_ATTR
+#endif
+template <class BoxT, int WIDTH, bool STATS>
+__global__ RT_TAIL_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk_shade(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
+                                                                           HitBuf hb, unsigned long long* counters, WalkShade sh) {
+    walk_body<BoxT, WIDTH, STATS, true>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -821,17 +860,18 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t
 }
 
 // One launched wave per logical wave of the queue.  The host does not know how many entries the queue holds (the
-// counts stay on the device), so it launches for an upper bound and the waves beyond the queue's end leave at once.
-// (A persistent grid-stride form of this kernel needs 147 instead of 90 VGPRs: three instead of five waves per SIMD.)
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
-                                                 HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
-    WaveQueue wq;
-    wq.load(qg, lane);
-    if (wave >= wq.n_waves) return;
+// counts stay on the device): it launches k_shade for its ESTIMATE of the queue's logical waves (the sizes the previous
+// passes reported through `hist`) and k_shade_rest, a small persistent grid, for every wave beyond that — whatever the
+// estimate, every entry is shaded exactly once.  Without an estimate k_shade covers the upper bound and the waves beyond
+// the queue's end leave at once.  hist (may be null): wave 0 stores the queue's entry count for the host's next estimate.
+// (The persistent grid-stride form needs 147 instead of 90 VGPRs — three instead of five waves per SIMD — so it only
+// takes the overflow.)
+template <bool LIGHT>
+__device__ __forceinline__ void shade_wave(const DScene& S, const PassParams& pp, uint32_t depth, const RayQueue& qi, const QueueGeom& qg,
+                                           const WaveQueue& wq, const HitBuf& hb, const RayQueue& qo, uint32_t* out_counts,
+                                           double* path_radiance, uint32_t wave, uint32_t lane) {
     uint32_t i = 0;
-    const bool active = wq.slot(wave, lane, i);
+    const bool active = LIGHT ? wq.slot_light(qg, wave, lane, i) : wq.slot(wave, lane, i);
     bool alive = false;
     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
     uint32_t pid = 0;
@@ -845,7 +885,32 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
         const double t = prim == RT_MISS ? 0.0 : hb.t[i];
         alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, t, hb, path_radiance, no, nd, nthr);
     }
-    queue_append(alive, wave, lane, qo, qg.shard_cap, out_counts, pid, no, nd, nthr);
+    queue_append(alive, wave, lane, qo, wq.shard_cap, out_counts, pid, no, nd, nthr);
+}
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
+                                                 HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance, uint32_t* hist) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    WaveQueue wq;
+    wq.load_light(qg);
+    if (wave >= wq.n_waves && !(hist && wave == 0)) return;
+    if (hist && wave == 0) {
+        uint32_t tot = wq.direct ? 0u : qg.count[COUNT_STRIDE * lane];
+        for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+        if (lane == 0) *hist = wq.direct ? wq.n_direct : tot;
+        if (wave >= wq.n_waves) return;
+    }
+    shade_wave<true>(S, pp, depth, qi, qg, wq, hb, qo, out_counts, path_radiance, wave, lane);
+}
+__global__ __launch_bounds__(BLOCK) void k_shade_rest(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
+                                                      HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance, uint32_t first_wave) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    const uint32_t n_launch = gridDim.x * (BLOCK / 64);
+    WaveQueue wq;
+    wq.load(qg, lane);
+    for (uint32_t wave = first_wave + wave0; wave < wq.n_waves; wave += n_launch)
+        shade_wave<false>(S, pp, depth, qi, qg, wq, hb, qo, out_counts, path_radiance, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -871,6 +936,44 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radianc
 __global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* mean, size_t n, double total_spp) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
+}
+
+// f64::round (half away from zero, like C's round) of a value already in [0, 255]
+__device__ __forceinline__ uint8_t round_u8(double x) { return (uint8_t)round(x); }
+__device__ __forceinline__ double clamp_colour(double c) {      // the reference panics outside [0, 1] (src/vec3.rs:44-63): clamp; NaN -> 0
+    if (!(c >= 0.0)) c = 0.0;
+    return c > 1.0 ? 1.0 : c;
+}
+
+// Output stage on the device: Vec3Ext::as_rgb_gamma (src/vec3.rs:71-97) over a resolved frame,
+// round(pow(c, 1/2.2) * 255) per channel, clamped like the host routine rt_encode_gamma8.
+__global__ __launch_bounds__(BLOCK) void k_gamma8(const double* mean, size_t n, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double gamma = 1.0 / 2.2;                       // as_gamma_vec (:39-42)
+    out[i] = round_u8(pow(clamp_colour(mean[i]), gamma) * 255.0);
+}
+
+// One pass of the preview loop's blend (window::render_thread, src/window.rs:277-310) for every pixel:
+//   new = pass_sum / n  (render_pixel's mean);  combined = new * (n / total) + old * (1 - n / total)
+// quantise: old is the 8-bit LINEAR frame / 255 and the result goes back through as_rgb_linear (round(c * 255)) — the
+// reference's accumulation; otherwise old is the float frame kept beside it (no re-quantisation error).  A = 0xff.
+__global__ __launch_bounds__(BLOCK) void k_blend_pass(const double* pass_sum, double* mean_frame, uint8_t* rgba8, size_t n_pixels,
+                                                      double n_samples, double total_samples, uint32_t quantise) {
+    const size_t px = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (px >= n_pixels) return;
+    const double new_ratio = n_samples / total_samples;   // :293
+    const double old_ratio = 1.0 - new_ratio;             // :294
+    uint8_t o[4];
+    for (int c = 0; c < 3; ++c) {
+        const double nw = pass_sum[3 * px + c] / n_samples;                           // src/camera.rs:324
+        const double old = quantise ? (double)rgba8[4 * px + c] / 255.0 : mean_frame[3 * px + c];
+        const double comb = (nw * new_ratio) + (old * old_ratio);                     // :295
+        mean_frame[3 * px + c] = comb;
+        o[c] = round_u8(clamp_colour(comb) * 255.0);                                 // as_rgb_linear (src/vec3.rs:64-68)
+    }
+    o[3] = 0xff;
+    *reinterpret_cast<uchar4*>(rgba8 + 4 * px) = make_uchar4(o[0], o[1], o[2], o[3]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pack_hits(HitBuf hb, QueueGeom qg, rt_hit* out) {
@@ -920,22 +1023,34 @@ static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFIL
 
 // n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
 template <class BoxT, int WIDTH, bool STATS, bool SHADE>
-static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
-                          unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, hipStream_t s) {
+static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
+                          HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, hipStream_t s) {
     const size_t lds = (size_t)stack_entries * TRACE_BLOCK * sizeof(uint32_t);
     // the occupancy query is per (kernel instance, stack size); a handful of values occur
     static unsigned cached_slots[5] = {0, 0, 0, 0, 0};
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
-    if (!cached_slots[ci]) cached_slots[ci] = resident_waves(k_walk<BoxT, WIDTH, STATS, SHADE>, lds);
+    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS>; else return k_walk<BoxT, WIDTH, STATS>; }();
+    if (!cached_slots[ci]) cached_slots[ci] = resident_waves(kernel, lds);
     const unsigned chunks = (n_upper + 63u) / 64u;
-    // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks
-    const unsigned slots = refill_enabled() ? std::min(refill_slots(cached_slots[ci]), chunks) : chunks;
+    // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks.
+    // The trace-and-shade kernel gets a share of the slots only (RT_HIP_TAIL_SLOTS): its queue is a few per cent of the pass,
+    // its waves hold twice the registers of the other kernels' and stay until their last path ends, so a full grid of them
+    // would shut the other passes in flight out of the SIMDs.
+    unsigned hw = cached_slots[ci];
+    // With an estimate of the queue's size (what the previous passes reported) the grid is sized for it — a wave per 64
+    // expected entries, a quarter more for safety; the waves are persistent, so any real size is still served in full.
+    if (n_estimate) hw = std::min<unsigned>(hw, std::max<unsigned>(64u, (n_estimate + n_estimate / 4 + 63u) / 64u));
+    if (SHADE) {
+        static const int ts = getenv("RT_HIP_TAIL_SLOTS") ? atoi(getenv("RT_HIP_TAIL_SLOTS")) : 0;
+        if (ts > 0) hw = (unsigned)ts;
+    }
+    const unsigned slots = refill_enabled() ? std::min(refill_slots(hw), chunks) : chunks;
     if (!slots) return;
-    hipLaunchKernelGGL((k_walk<BoxT, WIDTH, STATS, SHADE>), dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
+    hipLaunchKernelGGL(kernel, dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
 }
 template <class BoxT, int WIDTH>
-static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
-                          bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
+                          HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
     // The per-lane stack needs S.stack4 entries for the BVH4 and one entry per level for the BVH2; a smaller stack means
     // less LDS per wave, i.e. more waves per CU.
     const uint32_t need = WIDTH == 4 ? S.stack4 : S.bvh_depth;
@@ -943,40 +1058,41 @@ static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint
     WalkShade none;
     memset(&none, 0, sizeof(none));
     if (sh) {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, true>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, *sh, entries, s);
-        else launch_walk_k<BoxT, WIDTH, false, true>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, *sh, entries, s);
+        if (stats) launch_walk_k<BoxT, WIDTH, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, *sh, entries, s);
+        else launch_walk_k<BoxT, WIDTH, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, *sh, entries, s);
     } else {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, false>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, none, entries, s);
-        else launch_walk_k<BoxT, WIDTH, false, false>(S, q, qg, n_upper, t_min, t_max, hb, d_counters, none, entries, s);
+        if (stats) launch_walk_k<BoxT, WIDTH, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, none, entries, s);
+        else launch_walk_k<BoxT, WIDTH, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, none, entries, s);
     }
 }
-static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
-                            bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
+                            HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
     if (!n_upper) return;
     if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
-        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s); return; }
-        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s); return; }
+        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s); return; }
+        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s); return; }
     }
     if (S.nodes16)
-        launch_walk_b<Box16, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box16, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
     else if (S.nodes32)
-        launch_walk_b<Box32, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box32, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
     else
-        launch_walk_b<Box64, 2>(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box64, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
 }
 void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb, bool stats,
-                 unsigned long long* d_counters, hipStream_t s) {
-    launch_walk_any(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, nullptr, s);
+                 unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate) {
+    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, nullptr, s);
 }
 void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
-                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, bool stats, unsigned long long* d_counters,
-                       hipStream_t s) {
+                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
+                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate) {
     WalkShade sh;
     memset(&sh, 0, sizeof(sh));
     sh.pp = pp;
     sh.depth0 = depth0;
     sh.path_radiance = d_path_radiance;
-    launch_walk_any(S, q, qg, n_upper, t_min, t_max, hb, stats, d_counters, &sh, s);
+    sh.hist = d_hist;
+    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, &sh, s);
 }
 
 bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant
@@ -999,15 +1115,33 @@ void launch_trace_packet(const DScene& S, const PassParams* gen, RayQueue q, con
 #undef RT_LAUNCH_PACKET
 }
 
-// n_upper: upper bound of the queue's entries (sizes the launch; waves beyond the queue's end leave at once)
-void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper, HitBuf hb,
-                  RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, hipStream_t s) {
+// n_upper: upper bound of the queue's entries; n_estimate: what the host expects (0 = no idea): sizes the one-wave-per-wave
+// launch, the persistent k_shade_rest takes whatever lies beyond it.  d_hist: where the kernel reports the real count.
+void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueue q_in, const QueueGeom& qg, uint32_t n_upper,
+                  uint32_t n_estimate, HitBuf hb, RayQueue q_out, uint32_t* d_out_counts, double* d_path_radiance, uint32_t* d_hist,
+                  hipStream_t s, uint32_t exact_waves) {
     if (!n_upper) return;
+    if (exact_waves) {         // the caller knows the queue's logical waves (host-driven loop)
+        hipLaunchKernelGGL(k_shade, dim3((unsigned)(((size_t)exact_waves * 64u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qg,
+                           hb, q_out, d_out_counts, d_path_radiance, d_hist);
+        return;
+    }
     // logical waves: NSHARD * (waves of the longest shard) for a sharded queue — a shard holds at most shard_cap entries
     // and the whole queue at most n_upper
     const size_t bound = qg.count ? (size_t)NSHARD * ((std::min<size_t>(qg.shard_cap, n_upper) + 63u) / 64u) : ((size_t)n_upper + 63u) / 64u;
-    hipLaunchKernelGGL(k_shade, dim3((unsigned)((bound * 64u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qg, hb, q_out,
-                       d_out_counts, d_path_radiance);
+    size_t covered = bound;
+    if (qg.count && n_estimate) {
+        // shards fill evenly (each takes the survivors of every NSHARD-th input wave): longest shard ~ estimate / NSHARD
+        const size_t per_shard = (size_t)n_estimate / NSHARD + (size_t)n_estimate / (NSHARD * 16) + 256;
+        covered = std::min(bound, (size_t)NSHARD * ((per_shard + 63u) / 64u));
+    }
+    hipLaunchKernelGGL(k_shade, dim3((unsigned)((covered * 64u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qg, hb, q_out,
+                       d_out_counts, d_path_radiance, d_hist);
+    if (covered < bound) {
+        const size_t waves = std::min<size_t>(bound - covered, 1024);
+        hipLaunchKernelGGL(k_shade_rest, dim3((unsigned)((waves * 64u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, S, pp, depth, q_in, qg, hb,
+                           q_out, d_out_counts, d_path_radiance, (uint32_t)covered);
+    }
 }
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
                        uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s) {
@@ -1019,6 +1153,16 @@ void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint
 void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
+}
+void launch_gamma8(const double* d_mean, size_t n, uint8_t* d_out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gamma8, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_mean, n, d_out);
+}
+void launch_blend_pass(const double* d_pass_sum, double* d_mean_frame, uint8_t* d_rgba8, size_t n_pixels, uint32_t n_samples,
+                       uint64_t total_samples, bool quantise, hipStream_t s) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(k_blend_pass, dim3(grid_for(n_pixels)), dim3(BLOCK), 0, s, d_pass_sum, d_mean_frame, d_rgba8, n_pixels,
+                       (double)n_samples, (double)total_samples, quantise ? 1u : 0u);
 }
 void launch_pack_hits(HitBuf hb, const QueueGeom& qg, rt_hit* out, hipStream_t s) {
     if (!qg.n_direct) return;

@@ -164,6 +164,7 @@ struct RayQueue {
 // kernels of a whole pass without waiting for any of them.
 constexpr int NSHARD = 64;
 constexpr uint32_t COUNT_STRIDE = 32;            // u32 between two shard counters (128 B apart)
+constexpr uint32_t QUEUE_NWAVES_WORD = 1;        // count[1] (a gap word): the queue's logical waves, written by k_walk for k_shade
 struct QueueGeom {
     const uint32_t* count;      // device: count[COUNT_STRIDE * k] = live entries of shard k; nullptr = dense queue (below)
     uint32_t shard_cap;         // physical slots per shard (a multiple of 64)

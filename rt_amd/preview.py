@@ -18,10 +18,17 @@ SCHEDULE_RUNS = [(1, 1), (2, 1), (4, 1), (8, 2), (16, 2), (32, 2), (64, 84), (12
 SCHEDULE = [n for n, reps in SCHEDULE_RUNS for _ in range(reps)]
 
 
+def round_half_away(x):
+    """f64::round: ties away from zero (numpy's rint rounds ties to even)."""
+    r = np.rint(x)
+    tie = np.abs(x - np.trunc(x)) == 0.5
+    return np.where(tie, np.trunc(x) + np.sign(x), r)
+
+
 def as_rgb_linear(color):
-    """Vec3Ext::as_rgb_linear (src/vec3.rs:44-69): round(c * 255); the reference panics outside
+    """Vec3Ext::as_rgb_linear (src/vec3.rs:44-69): (c * 255).round(); the reference panics outside
     [0, 1], this clamps."""
-    return np.rint(np.clip(color, 0.0, 1.0) * 255.0).astype(np.uint8)
+    return round_half_away(np.clip(color, 0.0, 1.0) * 255.0).astype(np.uint8)
 
 
 def progressive(render, width, height, n_passes, seed=0, quantise=True, on_pass=None):
@@ -56,3 +63,24 @@ def render_with_preview(camera, world, n_passes=9, seed=0, quantise=True, on_pas
     """window::render_with_preview's render thread on the GPU path (headless)."""
     return progressive(lambda n, s: camera.render_image(world, spp=n, seed=s), camera.width, camera.height,
                        n_passes, seed, quantise, on_pass)
+
+
+def render_with_preview_device(camera, world, n_passes=9, seed=0, quantise=True, on_pass=None):
+    """The same loop with the frame kept on the GPU: one rt_render_pass per sweep (render + blend + 8-bit linear RGBA
+    read-back, no allocation and no float frame crossing PCIe per sweep).  Returns the (H, W, 3) uint8 frame (the float
+    frame with quantise=False) and the per-sweep stats, like render_with_preview."""
+    total, stats, t_first = 0, [], time.time()
+    frame = None
+    for k, n in enumerate(SCHEDULE[:n_passes]):
+        t0 = time.time()
+        total += n
+        rgba, mean = camera.render_pass(world, n, total, seed=seed + k, quantise=quantise, with_mean=True)
+        frame = rgba[..., :3] if quantise else mean
+        dt, dt_all = time.time() - t0, time.time() - t_first
+        st = {"pass": k + 1, "samples": n, "total_samples": total,
+              "mrays_per_s": n * camera.width * camera.height / 1e6 / max(dt, 1e-9),
+              "overall_mrays_per_s": total * camera.width * camera.height / 1e6 / max(dt_all, 1e-9)}
+        stats.append(st)
+        if on_pass:
+            on_pass(st, frame)
+    return frame, stats

@@ -1,0 +1,110 @@
+"""GPU tests of the ABI entries around the render path: the device output stage (f4), the progressive sweep entry
+(f2: rt_render_pass against rt_amd/preview.py's restatement of window::render_thread) and the single-process
+multi-GPU render (rt_render_multi: worker threads + RCCL sum-reduce; one device on the test box)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rt_amd import World, _abi, preview, scenes
+from rt_amd._lib import RtError, check, lib
+from rt_amd.api import encode_gamma8
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mixed():
+    desc = scenes.mixed_test_scene()
+    return desc, World.build(desc)
+
+
+def test_device_output_stage_matches_host_routine(mixed, oracle):
+    """rt_encode_gamma8_device on a device-resident frame == rt_encode_gamma8 on the host copy, byte for byte away from
+    rounding boundaries of round(c^(1/2.2) * 255) (the two pow() are glibc's and the GPU's), never more than one apart,
+    and == the oracle's orc_gamma8 of the same frame."""
+    from hip_mem import DeviceBuffer, synchronize
+    desc, world = mixed
+    cam = scenes.cam1(160, 120, max_depth=8)
+    img = cam.render_image(world, spp=6, seed=5)
+    special = np.array([0.0, 1.0, -0.25, 7.5, np.nan, 0.5, 1e-300, 0.21763764082403103])
+    frame = np.concatenate([img.reshape(-1), special])
+    d_in = DeviceBuffer.from_array(frame)
+    d_out = DeviceBuffer(frame.size)
+    check(lib().rt_encode_gamma8_device(d_in.ptr, frame.size, d_out.ptr, 0, None))
+    synchronize()
+    got = d_out.to_array(np.uint8, frame.size)
+    host = encode_gamma8(frame)
+    orc8 = np.zeros(frame.size, dtype=np.uint8)
+    oracle.lib().orc_gamma8(_abi.ptr(np.ascontiguousarray(np.nan_to_num(frame, nan=0.0))), frame.size, _abi.ptr(orc8))
+    scaled = np.clip(np.nan_to_num(frame, nan=0.0), 0.0, 1.0) ** (1.0 / 2.2) * 255.0
+    safe = np.abs(scaled - np.floor(scaled) - 0.5) > 1e-6
+    assert safe.mean() > 0.999
+    assert np.array_equal(got[safe], host[safe]) and np.array_equal(got[safe], orc8[safe])
+    assert (np.abs(got.astype(int) - host.astype(int)) <= 1).all()
+    assert got[-8:-3].tolist() == [0, 255, 0, 255, 0]           # 0, 1, negative, > 1, NaN: clamped, no panic
+
+
+def test_render_pass_matches_the_preview_loop(mixed):
+    """rt_render_pass sweep by sweep against preview.progressive over rt_render (same seeds): the float frame within
+    rounding of the blend, the 8-bit linear frame equal except where the float value sits on a rounding boundary,
+    in the reference's quantised accumulation and in the float one."""
+    desc, world = mixed
+    cam = scenes.cam1(96, 72, max_depth=8)
+    for quantise in (True, False):
+        frames = []
+        ref, _ = preview.progressive(lambda n, s: cam.render_image(world, spp=n, seed=s), 96, 72, 6, seed=11, quantise=quantise,
+                                     on_pass=lambda st, f: frames.append(np.array(f)))
+        total = 0
+        for k, n in enumerate(preview.SCHEDULE[:6]):
+            total += n
+            rgba, mean, st = cam.render_pass(world, n, total, seed=11 + k, quantise=quantise, with_mean=True, with_stats=True)
+            assert int(st["samples"]) == 96 * 72 * n and (rgba[..., 3] == 255).all()
+            if quantise:
+                diff = np.abs(rgba[..., :3].astype(int) - frames[k].astype(int))
+                assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, (k, diff.max(), (diff != 0).mean())
+            else:
+                np.testing.assert_allclose(mean, frames[k], rtol=1e-12, atol=1e-15)
+                assert np.abs(rgba[..., :3].astype(int) - preview.as_rgb_linear(frames[k]).astype(int)).max() <= 1
+    dev, stats = preview.render_with_preview_device(cam, world, n_passes=4, seed=2, quantise=True)
+    host, _ = preview.render_with_preview(cam, world, n_passes=4, seed=2, quantise=True)
+    assert dev.shape == host.shape == (72, 96, 3) and np.abs(dev.astype(int) - host.astype(int)).max() <= 1
+    assert [s["total_samples"] for s in stats] == [1, 3, 7, 15]
+
+
+def test_render_pass_argument_checks(mixed):
+    desc, world = mixed
+    cam = scenes.cam1(32, 24, max_depth=4)
+    L = lib()
+    rgba = np.zeros((24, 32, 4), np.uint8)
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 0, 0, 0, 1, _abi.ptr(rgba), None, None) == _abi.RT_ERR_INVALID
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 4, 2, 0, 1, _abi.ptr(rgba), None, None) == _abi.RT_ERR_INVALID
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 1, 1, 0, 8, _abi.ptr(rgba), None, None) == _abi.RT_ERR_INVALID
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 1, 1, 0, 1, _abi.ptr(rgba), None, None) == _abi.RT_OK
+    # the running total must continue where the frame stands
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 2, 5, 0, 1, _abi.ptr(rgba), None, None) == _abi.RT_ERR_INVALID
+    assert L.rt_render_pass(world._h, _abi.ptr(cam.rec), 2, 3, 0, 1, None, None, None) == _abi.RT_OK
+
+
+def test_render_multi_one_device_equals_rt_render(mixed):
+    """rt_render_multi with one device goes through the worker thread, ncclCommInitAll and ncclReduce and must give
+    rt_render's image bit for bit; the same samples split by hand over two 'ranks' sum to it."""
+    desc, world = mixed
+    cam = scenes.cam1(80, 60, max_depth=8)
+    ref, rst = cam.render_image(world, spp=7, seed=9, with_stats=True)
+    img, st = cam.render_image_multi([world], spp=7, seed=9, with_stats=True)
+    assert np.array_equal(img, ref)
+    assert int(st[0]["ray_segments"]) == int(rst["ray_segments"]) and int(st[0]["samples"]) == 80 * 60 * 7
+    again = cam.render_image_multi([world], spp=7, seed=9)                 # the communicator is reused
+    assert np.array_equal(again, ref)
+    # what two devices would render: sample indices 0,2,4,6 and 1,3,5
+    a = cam.render_image(world, spp=4, seed=9, sample_offset=0, sample_stride=2)
+    b = cam.render_image(world, spp=3, seed=9, sample_offset=1, sample_stride=2)
+    np.testing.assert_allclose((4.0 * a + 3.0 * b) / 7.0, ref, rtol=1e-12, atol=1e-15)
+    L = lib()
+    out = np.zeros((60, 80, 3))
+    o = cam.opts(spp=7, seed=9)
+    handles = (C.c_void_p * 2)(world._h, world._h)
+    assert L.rt_render_multi(handles, 2, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID
+    assert b"same device" in L.rt_last_error()
+    assert L.rt_render_multi(handles, 0, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID

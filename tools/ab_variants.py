@@ -33,13 +33,30 @@ def build(specs):
 
 
 def run(args):
-    names = ["base"] + sorted(os.listdir(VDIR)) if os.path.isdir(VDIR) else ["base"]
+    # entries: base (in-tree library), r1 (the round-1 tree under build/old/r1, if present: the reference point on THIS box —
+    # boxes differ by several per cent), every library under build/variants, and NAME=VALUE[,NAME=VALUE] environment settings
+    # given before the bench arguments (up to a "--")
+    envs = []
+    if "--" in args:
+        k = args.index("--")
+        envs, args = args[:k], args[k + 1:]
+    names = ["base"] + (["r1"] if os.path.isdir(os.path.join(ROOT, "build", "old", "r1")) else []) + \
+            (sorted(os.listdir(VDIR)) if os.path.isdir(VDIR) else []) + ["env:" + e for e in envs]
     for rnd in range(2):
         for n in names:
             env = dict(os.environ)
-            if n != "base":
+            bench = os.path.join(ROOT, "bench.py")
+            cwd = ROOT
+            if n == "r1":
+                cwd = os.path.join(ROOT, "build", "old", "r1")
+                bench = os.path.join(cwd, "bench.py")
+            elif n.startswith("env:"):
+                for kv in n[4:].split(","):
+                    a, _, b = kv.partition("=")
+                    env[a] = b
+            elif n != "base":
                 env["RT_HIP_LIB"] = os.path.join(VDIR, n, "librt_hip.so")
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-alone"] + args, env=env,
+            r = subprocess.run([sys.executable, bench, "--no-cpu-baseline", "--no-alone"] + args, env=env, cwd=cwd,
                                capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:
@@ -47,9 +64,8 @@ def run(args):
                 continue
             j = json.loads(line[-1])
             rf = j["roofline"]
-            print(f"{n:24s} r{rnd} value={j['value']:8.1f} ms/step={j['ms_per_step']:8.2f} trace={j['trace_fraction_of_step'] * j['ms_per_step']:7.2f}ms "
-                  f"shade={j['shade_fraction_of_step'] * j['ms_per_step']:7.2f}ms bounce_rays/s={rf['rays_per_s'] / 1e9:.3f}G "
-                  f"packet_rays/s={j['roofline_packet']['rays_per_s'] / 1e9:.3f}G", flush=True)
+            print(f"{n:34s} r{rnd} value={j['value']:8.1f} ms/step={j['ms_per_step']:8.2f} "
+                  f"bounce_rays/s={rf['rays_per_s'] / 1e9:.3f}G packet_rays/s={j['roofline_packet']['rays_per_s'] / 1e9:.3f}G", flush=True)
 
 
 if __name__ == "__main__":
