@@ -327,16 +327,14 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
         const bool at_leaf = !at_node && cur != REF_EMPTY;
         const unsigned long long m_live = __ballot(at_node || at_leaf);
         bool more = chunk_pos < 64u || next_chunk < n_chunks;
-        bool service;
-        if (SHADE) {
-            // lanes with something to do in the block below: finished traversals (to shade), and idle lanes while rays are left
+        // SHADE: lanes with something to do in the block below = finished traversals (to shade) + idle lanes while rays are left
+        auto shade_service = [&]() -> bool {
             const int n_fin = __popcll(__ballot(busy && cur == REF_EMPTY));
             const int n_idle = more ? __popcll(__ballot(!busy)) : 0;
-            service = !m_live || n_fin + n_idle >= RT_REFILL_T;
-        } else {
-            service = !m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T);
-        }
-        if (service) {
+            return !m_live || n_fin + n_idle >= RT_REFILL_T;
+        };
+        // (the condition sits in the `if` itself: as a bool variable it cost six VALU instructions per iteration)
+        if (SHADE ? shade_service() : (!m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T))) {
             if (busy && cur == REF_EMPTY) {                           // retire
                 if (SHADE) {
                     ++n_seg;
@@ -891,16 +889,37 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
                                                  HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance, uint32_t* hist) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
-    WaveQueue wq;
-    wq.load_light(qg);
-    if (wave >= wq.n_waves && !(hist && wave == 0)) return;
-    if (hist && wave == 0) {
-        uint32_t tot = wq.direct ? 0u : qg.count[COUNT_STRIDE * lane];
-        for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
-        if (lane == 0) *hist = wq.direct ? wq.n_direct : tot;
-        if (wave >= wq.n_waves) return;
+    // A wave of this kernel lives for a few microseconds, so its start-up chain matters: the two words of the queue's
+    // counters it needs (size in waves — left by the traversal kernel —, its own shard's count) and the ray + hit record of
+    // its slot are all requested at once; the slot's address does not depend on the counts, and every slot of a shard is
+    // allocated memory, so the loads are safe even where the entry turns out not to exist.
+    const uint32_t shard = wave & (NSHARD - 1);
+    const uint32_t off = (wave / NSHARD) * 64u + lane;
+    const uint32_t i = shard * qg.shard_cap + off;
+    const bool direct = qg.count == nullptr;
+    const uint32_t pid = qi.pid[i];
+    const D3 o = mk(qi.o[0][i], qi.o[1][i], qi.o[2][i]);
+    const D3 d = mk(qi.d[0][i], qi.d[1][i], qi.d[2][i]);
+    // depth 0: the throughput is (1,1,1) by construction (k_raygen writes it, nobody needs to read it)
+    const D3 thr = depth == 0 ? mk(1.0, 1.0, 1.0) : mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
+    const uint32_t prim = hb.prim[i];
+    const double t_hit = hb.t[i];
+    // (after the vector loads in program order: scalar loads return out of order, so waiting for these two means waiting
+    // for all of them — issued first they would hold the ray loads back by a round trip)
+    uint32_t n_waves = (qg.n_direct + 63u) >> 6, c_shard = 0;
+    if (!direct) { n_waves = qg.count[QUEUE_NWAVES_WORD]; c_shard = qg.count[COUNT_STRIDE * shard]; }
+    if (hist && wave == 0) {           // the queue's entry count, for the host's next launch estimate
+        uint32_t tot = direct ? 0u : qg.count[COUNT_STRIDE * lane];
+        for (int sh = 32; sh; sh >>= 1) tot += (uint32_t)__shfl_xor((int)tot, sh);
+        if (lane == 0) *hist = direct ? qg.n_direct : tot;
     }
-    shade_wave<true>(S, pp, depth, qi, qg, wq, hb, qo, out_counts, path_radiance, wave, lane);
+    if (wave >= n_waves) return;
+    const bool active = direct ? wave * 64u + lane < qg.n_direct : off < c_shard;
+    bool alive = false;
+    D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
+    if (active)
+        alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, prim == RT_MISS ? 0.0 : t_hit, hb, path_radiance, no, nd, nthr);
+    queue_append(alive, wave, lane, qo, qg.shard_cap, out_counts, active ? pid : 0u, no, nd, nthr);
 }
 __global__ __launch_bounds__(BLOCK) void k_shade_rest(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
                                                       HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance, uint32_t first_wave) {
