@@ -400,6 +400,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     pp0.jitter = 1;
     pp0.tiled = 1;
     pp0.group = 1;
+    pp0.jitter_table = nullptr;
     // samples of a pixel that share a wave of camera rays: as many as the pass and the frame allow
     // (RT_HIP_GROUP=1|4|16|64 caps it; 1 = one sample of an 8x8 tile per wave)
     const int ge = env_int("RT_HIP_GROUP", 0);
@@ -489,6 +490,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         pp.pass_base = base;
         for (uint32_t g = 64; g > 1; g >>= 2)
             if (g <= group_cap && nl % g == 0 && npix % (64u / g) == 0) { pp.group = g; break; }
+        finish_pass_params(pp);
         const uint32_t scap = shard_cap_for(n);
         const QueueGeom dense = {nullptr, scap, n};
         uint32_t* cnt[2] = {w.counters, w.counters + COUNTER_BYTES / 4};
@@ -682,6 +684,7 @@ int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts
         P.pp.pass_base = base;
         for (uint32_t g = 64; g > 1; g >>= 2)
             if (g <= group_cap && P.nl % g == 0 && npix % (64u / g) == 0) { P.pp.group = g; break; }
+        finish_pass_params(P.pp);
         P.scap = shard_cap_for(P.n);
         const QueueGeom dense = {nullptr, P.scap, P.n};
         HIPCHK(hipMemsetAsync(w.counters, 0, 2 * COUNTER_BYTES, P.s));
@@ -1220,6 +1223,8 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     pp.jitter = jitter ? 1 : 0;
     pp.tiled = 0;
     pp.group = 1;
+    pp.jitter_table = nullptr;
+    finish_pass_params(pp);
     hipStream_t stream = nullptr;
     const QueueGeom qm = {nullptr, shard_cap_for(npix), (uint32_t)npix};
     launch_raygen(pp, qm, w.q[0], stream);

@@ -125,6 +125,58 @@ __device__ __forceinline__ size_t slot_sample_to_pid(uint32_t slot, uint32_t loc
     return (size_t)(local / G) * ((size_t)n_pixels * G) + (size_t)(slot / P) * 64u + (local % G) * P + (slot % P);
 }
 
+// ---- path id -> (pixel, x, y, local sample) with the pass's precomputed divisors ------------------
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t m, uint32_t s1, uint32_t s2) {
+    const uint32_t t = __umulhi(m, x);
+    return (t + ((x - t) >> s1)) >> s2;
+}
+struct PathIndex {
+    uint32_t pixel, x, y, local;
+};
+// the same mapping as pid_to_slot_sample + slot_to_pixel (tested equal), one mul_hi division instead of five u32 divisions
+template <class PP>
+__device__ __forceinline__ PathIndex decode_path(const PP& pp, uint32_t pid) {
+    PathIndex r;
+    uint32_t slot;
+    const uint32_t q = fast_div(pid, pp.div_group.m, pp.div_group.s1, pp.div_group.s2);       // pid / (n_pixels * G)
+    const uint32_t rem = pid - q * pp.div_group.d;
+    if (pp.group <= 1u) {
+        r.local = q;
+        slot = rem;
+    } else {
+        const uint32_t lane = rem & 63u, pm1 = (1u << pp.log2_p) - 1u;
+        slot = ((rem >> 6) << pp.log2_p) + (lane & pm1);
+        r.local = q * pp.group + (lane >> pp.log2_p);
+    }
+    const uint32_t W = pp.cam.width, H = pp.cam.height;
+    if (!pp.tiled) {
+        r.pixel = slot;
+        r.y = fast_div(slot, pp.div_width.m, pp.div_width.s1, pp.div_width.s2);
+        r.x = slot - r.y * W;
+        return r;
+    }
+    const uint32_t W8 = W & ~7u, H8 = H & ~7u, nfull = W8 * H8;
+    if (slot < nfull) {
+        const uint32_t tile = slot >> 6, in = slot & 63u;
+        const uint32_t ty = fast_div(tile, pp.div_tpr.m, pp.div_tpr.s1, pp.div_tpr.s2), tx = tile - ty * pp.div_tpr.d;
+        r.x = tx * 8u + compact3(in);
+        r.y = ty * 8u + compact3(in >> 1);
+    } else {                                  // the strips beside / below the full tiles (sizes that are not multiples of 8)
+        uint32_t k = slot - nfull;
+        const uint32_t wr = W - W8;
+        if (k < wr * H8) {
+            r.x = W8 + k % wr;
+            r.y = k / wr;
+        } else {
+            k -= wr * H8;
+            r.x = k % W;
+            r.y = H8 + k / W;
+        }
+    }
+    r.pixel = r.y * W + r.x;
+    return r;
+}
+
 // ---- sharded queue addressing ----------------------------------------------------------------
 // A wave's view of a queue: the shard counts are read once per wave from device memory (lane k keeps shard k's) and
 // looked up with v_readlane; a dense queue needs no memory at all.

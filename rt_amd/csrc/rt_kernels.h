@@ -14,6 +14,13 @@ namespace rt {
 #endif
 constexpr int BLOCK = RT_BLOCK;
 
+// Exact u32 division by a divisor that is fixed for a pass (Granlund-Montgomery: one mul_hi, two shifts, an add and a
+// subtract instead of the ~25-instruction expansion of a u32 division; the path-id decode runs once per path vertex).
+struct FastDiv {
+    uint32_t m, s1, s2, d;
+};
+FastDiv fast_div_for(uint32_t d);            // d >= 1
+
 struct PassParams {
     rt_camera cam;
     uint64_t seed;
@@ -23,7 +30,15 @@ struct PassParams {
     uint32_t jitter;                         // 0: debug_ray (pixel centres, pinhole)
     uint32_t tiled;                          // 1: path slots enumerate pixels in 8x8 tiles (coherent waves)
     uint32_t group;                          // samples of a pixel per wave of camera rays (rt_device.h: pid_to_slot_sample)
+    // derived by finish_pass_params() from the fields above
+    uint32_t log2_p;                         // log2(64 / group)
+    FastDiv div_group;                       // by n_pixels * group (the paths of one sample group; n_pixels when group <= 1)
+    FastDiv div_tpr;                         // by the full 8x8 tiles per row
+    FastDiv div_width;                       // by the image width
+    const double* jitter_table;              // optional: Halton (2, 3) pairs of the pass's local samples, [2 * local]
 };
+// call after n_pixels / group / cam / tiled are set and before the struct goes to a kernel
+void finish_pass_params(PassParams& pp);
 
 // ---- device statistics: groups of STAT_GROUP u64 counters, one group per kind of launch ----------
 constexpr int STAT_GROUP = 16;

@@ -28,15 +28,16 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // K0 — primary rays
 // ---------------------------------------------------------------------------------------------
-// Camera::get_ray for path id `pid` of the pass (src/camera.rs:231-254)
-__device__ __forceinline__ void camera_ray(const PassParams& pp, uint32_t pid, D3& origin, D3& dir) {
-    uint32_t local, pslot;
-    pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
-    uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
-    uint32_t sample = pp.sample_offset + (pp.pass_base + local) * pp.sample_stride;
-    uint32_t x = pixel % pp.cam.width, y = pixel / pp.cam.width;
-    double ox = pp.jitter ? halton2(sample) : 0.0;      // rng_map[i] (src/camera.rs:239)
-    double oy = pp.jitter ? halton3(sample) : 0.0;
+// Camera::get_ray for the path with index `ix` of the pass (src/camera.rs:231-254)
+__device__ __forceinline__ void camera_ray(const PassParams& pp, const PathIndex& ix, D3& origin, D3& dir) {
+    const uint32_t pixel = ix.pixel, x = ix.x, y = ix.y;
+    const uint32_t sample = pp.sample_offset + (pp.pass_base + ix.local) * pp.sample_stride;
+    // rng_map[i] (src/camera.rs:239): from the pass's table when the host provided one (exact rationals either way)
+    double ox = 0.0, oy = 0.0;
+    if (pp.jitter) {
+        if (pp.jitter_table) { ox = pp.jitter_table[2 * ix.local]; oy = pp.jitter_table[2 * ix.local + 1]; }
+        else { ox = halton2(sample); oy = halton3(sample); }
+    }
     D3 p00 = ld3(pp.cam.pixel00), du = ld3(pp.cam.pixel_du), dv = ld3(pp.cam.pixel_dv), center = ld3(pp.cam.center);
     D3 ps = add(add(p00, scale(du, (double)x + ox)), scale(dv, (double)y + oy));
     origin = center;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueGeom qg, R
     uint32_t slot = 0;
     if (!direct_slot(qg, pid, slot)) return;
     D3 origin, dir;
-    camera_ray(pp, pid, origin, dir);
+    camera_ray(pp, decode_path(pp, pid), origin, dir);
     q.o[0][slot] = origin.x; q.o[1][slot] = origin.y; q.o[2][slot] = origin.z;
     q.d[0][slot] = dir.x; q.d[1][slot] = dir.y; q.d[2][slot] = dir.z;
     q.pid[slot] = pid;                                   // (throughput starts at 1: k_shade does not read it at depth 0)
@@ -235,9 +236,9 @@ constexpr int TRACE_BLOCK = 64;
 #define RT_TRACE_WAVES 1
 #endif
 
-__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
-                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
-                                           double* path_radiance, D3& no, D3& nd, D3& nthr);
+__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t pixel,
+                                           uint32_t local, uint32_t i, const D3 o, const D3 d, const D3 thr, uint32_t prim, double t,
+                                           const HitBuf& hb, double* path_radiance, D3& no, D3& nd, D3& nthr);
 __device__ __forceinline__ void queue_append(bool alive, uint32_t wave, uint32_t lane, const RayQueue& qo, uint32_t shard_cap,
                                              uint32_t* out_counts, uint32_t pid, const D3 no, const D3 nd, const D3 nthr);
 
@@ -339,7 +340,8 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 if (SHADE) {
                     ++n_seg;
                     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
-                    const bool alive = shade_path(S, sh.pp, depth, pid, slot, o, d, thr, prim, best, hb, sh.path_radiance, no, nd, nthr);
+                    const PathIndex ix = decode_path(sh.pp, pid);
+                    const bool alive = shade_path(S, sh.pp, depth, pid, ix.pixel, ix.local, slot, o, d, thr, prim, best, hb, sh.path_radiance, no, nd, nthr);
                     if (alive) {                                      // Camera::raycast's recursion (src/camera.rs:303): the same lane goes on
                         o = no; d = nd; thr = nthr; ++depth;
                         rb.init(S, o, d, t_min, t_max);
@@ -585,10 +587,12 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
     uint32_t i = 0;
     const bool active = direct_slot(qg, blockIdx.x * TRACE_BLOCK + lane, i);      // camera rays: always a dense queue
     D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+    PathIndex ix = {0u, 0u, 0u, 0u};          // decoded once: the camera ray and the depth-0 shading share it
     if (active) {
         if (GEN) {
             const uint32_t pid = blockIdx.x * TRACE_BLOCK + lane;
-            camera_ray(pp, pid, o, d);
+            ix = decode_path(pp, pid);
+            camera_ray(pp, ix, o, d);
             if (!FUSE) {
                 q.o[0][i] = o.x; q.o[1][i] = o.y; q.o[2][i] = o.z;
                 q.d[0][i] = d.x; q.d[1][i] = d.y; q.d[2][i] = d.z;
@@ -712,7 +716,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         const uint32_t pid = blockIdx.x * TRACE_BLOCK + lane;
         if (active) {
             if (prim != RT_MISS) { hb.bu[i] = bu; hb.bv[i] = bv; }      // read back only by textured triangles
-            alive = shade_path(S, pp, 0u, pid, i, o, d, mk(1.0, 1.0, 1.0), prim, best, hb, path_radiance, no, nd, nthr);
+            alive = shade_path(S, pp, 0u, pid, ix.pixel, ix.local, i, o, d, mk(1.0, 1.0, 1.0), prim, best, hb, path_radiance, no, nd, nthr);
         }
         queue_append(alive, blockIdx.x, lane, qo, qg.shard_cap, out_counts, pid, no, nd, nthr);
     } else if (active) {
@@ -742,9 +746,10 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
 // One path vertex: sky on a miss, else the intersection record, Material::scatter and russian_roulette.
 // Returns whether the path goes on (then no, nd, nthr are the next ray and throughput); a path that ends
 // writes its radiance slot.  bu/bv are read lazily through hb (only textured triangles need them).
-__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t i,
-                                           const D3 o, const D3 d, const D3 thr, uint32_t prim, double t, const HitBuf& hb,
-                                           double* path_radiance, D3& no, D3& nd, D3& nthr) {
+// pixel / local: the path's pixel index and local sample (decode_path of pid), for the RNG key.
+__device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp, uint32_t depth, uint32_t pid, uint32_t pixel,
+                                           uint32_t local, uint32_t i, const D3 o, const D3 d, const D3 thr, uint32_t prim, double t,
+                                           const HitBuf& hb, double* path_radiance, D3& no, D3& nd, D3& nthr) {
     bool alive = false;
     D3 L = mk(0.0, 0.0, 0.0);
     if (prim == RT_MISS) {
@@ -774,9 +779,6 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
         }
         const ShadeMat* m = &S.mats[h.material];
         const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
-        uint32_t local, pslot;
-        pid_to_slot_sample(pid, pp.n_pixels, pp.group, pslot, local);
-        const uint32_t pixel = slot_to_pixel(pslot, pp.cam.width, pp.cam.height, pp.tiled);
         RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
         D3 att, dir;
         if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
@@ -881,7 +883,8 @@ __device__ __forceinline__ void shade_wave(const DScene& S, const PassParams& pp
         const D3 thr = depth == 0 ? mk(1.0, 1.0, 1.0) : mk(qi.thr[0][i], qi.thr[1][i], qi.thr[2][i]);
         const uint32_t prim = hb.prim[i];
         const double t = prim == RT_MISS ? 0.0 : hb.t[i];
-        alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, t, hb, path_radiance, no, nd, nthr);
+        const PathIndex ix = decode_path(pp, pid);
+        alive = shade_path(S, pp, depth, pid, ix.pixel, ix.local, i, o, d, thr, prim, t, hb, path_radiance, no, nd, nthr);
     }
     queue_append(alive, wave, lane, qo, wq.shard_cap, out_counts, pid, no, nd, nthr);
 }
@@ -917,8 +920,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32
     const bool active = direct ? wave * 64u + lane < qg.n_direct : off < c_shard;
     bool alive = false;
     D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
-    if (active)
-        alive = shade_path(S, pp, depth, pid, i, o, d, thr, prim, prim == RT_MISS ? 0.0 : t_hit, hb, path_radiance, no, nd, nthr);
+    if (active) {
+        const PathIndex ix = decode_path(pp, pid);
+        alive = shade_path(S, pp, depth, pid, ix.pixel, ix.local, i, o, d, thr, prim, prim == RT_MISS ? 0.0 : t_hit, hb, path_radiance, no, nd, nthr);
+    }
     queue_append(alive, wave, lane, qo, qg.shard_cap, out_counts, active ? pid : 0u, no, nd, nthr);
 }
 __global__ __launch_bounds__(BLOCK) void k_shade_rest(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
@@ -1015,6 +1020,27 @@ __global__ __launch_bounds__(BLOCK) void k_pack_rays(RayQueue q, QueueGeom qg, r
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+FastDiv fast_div_for(uint32_t d) {
+    FastDiv f;
+    if (d == 0) d = 1;
+    uint32_t L = 0;
+    while ((1ull << L) < d) ++L;                           // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    f.s1 = L < 1 ? L : 1;
+    f.s2 = L > 0 ? L - 1 : 0;
+    f.d = d;
+    return f;
+}
+void finish_pass_params(PassParams& pp) {
+    const uint32_t G = pp.group <= 1u ? 1u : pp.group;
+    uint32_t lp = 0;
+    while ((64u >> lp) > G) ++lp;                          // 64 / G = 2^lp
+    pp.log2_p = G == 1u ? 6u : lp;
+    pp.div_group = fast_div_for(pp.group <= 1u ? std::max(pp.n_pixels, 1u) : pp.n_pixels * G);
+    pp.div_tpr = fast_div_for(std::max((pp.cam.width & ~7u) >> 3, 1u));
+    pp.div_width = fast_div_for(std::max(pp.cam.width, 1u));
+}
+
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 void launch_raygen(const PassParams& pp, const QueueGeom& qg, RayQueue q, hipStream_t s) {
