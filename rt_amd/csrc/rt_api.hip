@@ -139,6 +139,8 @@ struct Workspace {
     uint32_t* counters = nullptr;                  // 2 sets of NSHARD queue counters, 128 B apart (device only: no host copy exists)
     uint32_t* hist = nullptr;                      // HIST_DEPTHS u32 right behind them: queue sizes the kernels report per pass
     uint32_t* h_hist = nullptr;                    // pinned copy, read when the pipe is reused (launch estimates only)
+    double* jitter = nullptr;                      // Halton table of the pass in flight (2 doubles per local sample)
+    size_t jitter_cap = 0;                         // in samples
     unsigned long long* stat_counters = nullptr;   // STAT_GROUPS groups of STAT_GROUP u64
     unsigned long long* h_stat = nullptr;          // pinned copy of them
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the pass in flight
@@ -176,6 +178,7 @@ void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
     if (w.h_stat) (void)hipHostFree(w.h_stat);
     if (w.h_hist) (void)hipHostFree(w.h_hist);
+    if (w.jitter) (void)hipFree(w.jitter);
     for (auto& e : w.ev)
         if (e) (void)hipEventDestroy(e);
     w = Workspace();
@@ -366,6 +369,16 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         n_passes = (opts->spp + per_pass - 1) / per_pass;
         n_pipes = (int)std::min<uint32_t>(n_passes, (uint32_t)n_pipes);
     }
+    for (int k = 0; k < n_pipes; ++k) {          // per-pass Halton tables (16 B per sample of a pass; optional: a failed allocation only disables them)
+        Workspace& w = sc->ws[k];
+        if (w.jitter_cap < per_pass) {
+            if (w.jitter) (void)hipFree(w.jitter);
+            w.jitter = nullptr;
+            w.jitter_cap = 0;
+            if (hipMalloc((void**)&w.jitter, (size_t)per_pass * 2 * sizeof(double)) == hipSuccess) w.jitter_cap = per_pass;
+            else (void)hipGetLastError();
+        }
+    }
     if (!sc->ev_fork) {
         HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -490,6 +503,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         pp.pass_base = base;
         for (uint32_t g = 64; g > 1; g >>= 2)
             if (g <= group_cap && nl % g == 0 && npix % (64u / g) == 0) { pp.group = g; break; }
+        if (w.jitter_cap >= nl && !getenv("RT_HIP_NO_JITTER_TABLE")) {
+            pp.jitter_table = w.jitter;
+            launch_jitter_table(pp, nl, w.jitter, P.s);
+            st.launches++;
+        }
         finish_pass_params(pp);
         const uint32_t scap = shard_cap_for(n);
         const QueueGeom dense = {nullptr, scap, n};

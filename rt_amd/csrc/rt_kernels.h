@@ -54,6 +54,8 @@ enum {
 };
 constexpr size_t STAT_BYTES = 512;                  // >= STAT_GROUPS * STAT_GROUP * 8
 
+// the pass's Halton table (2 doubles per local sample) for PassParams::jitter_table
+void launch_jitter_table(const PassParams& pp, uint32_t n_local, double* d_out, hipStream_t s);
 // K0: primary rays for path ids [0, n) -> dense queue
 void launch_raygen(const PassParams& pp, const QueueGeom& qg, RayQueue q, hipStream_t s);
 // World::hit input for rt_trace_closest: normalise host rays into a dense queue (Ray::new)

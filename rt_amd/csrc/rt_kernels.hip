@@ -55,6 +55,17 @@ __device__ __forceinline__ void camera_ray(const PassParams& pp, const PathIndex
     dir = normalize(sub(ps, origin));                    // Ray::new normalises
 }
 
+// rng_map of one pass (src/camera.rs:208-210): the Halton (2, 3) pair of every local sample, computed once instead of once
+// per camera ray (the base-3 radical inverse is a loop of divisions).  out[2 * local] = H2, out[2 * local + 1] = H3.
+__global__ __launch_bounds__(BLOCK) void k_jitter_table(uint32_t sample_offset, uint32_t sample_stride, uint32_t pass_base, uint32_t n_local,
+                                                        double* out) {
+    const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
+    if (local >= n_local) return;
+    const uint32_t sample = sample_offset + (pass_base + local) * sample_stride;
+    out[2 * local] = halton2(sample);
+    out[2 * local + 1] = halton3(sample);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_raygen(PassParams pp, QueueGeom qg, RayQueue q) {
     const uint32_t pid = blockIdx.x * BLOCK + threadIdx.x;       // logical entry = path id
     uint32_t slot = 0;
@@ -1043,6 +1054,10 @@ void finish_pass_params(PassParams& pp) {
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
+void launch_jitter_table(const PassParams& pp, uint32_t n_local, double* d_out, hipStream_t s) {
+    if (!n_local) return;
+    hipLaunchKernelGGL(k_jitter_table, dim3(grid_for(n_local)), dim3(BLOCK), 0, s, pp.sample_offset, pp.sample_stride, pp.pass_base, n_local, d_out);
+}
 void launch_raygen(const PassParams& pp, const QueueGeom& qg, RayQueue q, hipStream_t s) {
     if (!qg.n_direct) return;
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, pp, qg, q);
