@@ -113,9 +113,9 @@ def pmc_traffic(workload):
         return next((v.get(key) for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
                      if n.startswith(pre) and n.rstrip().endswith(suf)), None)
 
-    # stand-alone traversal = k_walk<..., SHADE = false>; the r01 summaries name it k_trace4
-    walk = lambda key: pick("k_walk<", key, "false>") if pick("k_walk<", key, "false>") is not None else pick("k_trace4<", key)
-    valu = {"k_walk": walk("valu_active_per_simd_cycle"), "k_walk_tail": pick("k_walk<", "valu_active_per_simd_cycle", "true>"),
+    # stand-alone traversal = k_walk<...> (the r01 summaries name it k_trace4); persistent trace-and-shade = k_walk_shade<...>
+    walk = lambda key: pick("k_walk<", key) if pick("k_walk<", key) is not None else pick("k_trace4<", key)
+    valu = {"k_walk": walk("valu_active_per_simd_cycle"), "k_walk_shade": pick("k_walk_shade<", "valu_active_per_simd_cycle"),
             "k_trace_packet": pick("k_trace_packet", "valu_active_per_simd_cycle"),
             "k_shade": pick("k_shade", "valu_active_per_simd_cycle")}
     return walk("traffic_bytes_per_launch"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
@@ -361,7 +361,8 @@ def main():
                                 "bytes_per_wave": p_bytes_per_wave, "node_fetches_per_wave": wv_n, "prim_fetches_per_wave": wv_p,
                                 "nodes_per_ray": int(sst["nodes_visited_primary"]) / s_pseg,
                                 "rays_per_s": prim_seg / prim_s if prim_s > 0 else 0.0},
-            "tail_kernel": {"kernel": "k_walk<SHADE> (persistent trace + shade of every bounce from depth 2 on, one launch per pass)",
+            "tail_kernel": {"kernel": "every bounce from depth 2 on: stand-alone k_walk + k_shade pairs while the queues are large, then k_walk_shade "
+                                      "(persistent trace + shade, one launch per pass) for the rest",
                             "segments": tail_seg, "avg_launch_ms": tail_s / max(1, n_passes) * 1e3,
                             "rays_per_s": tail_seg / tail_s if tail_s > 0 else 0.0},
             "trace_fraction_of_step": (prim_s + bounce_s) / dt, "shade_fraction_of_step": shade_s / dt, "tail_fraction_of_step": tail_s / dt,

@@ -142,11 +142,13 @@ typedef struct rt_stats {
     uint64_t nodes_visited_primary; /* parts of nodes_visited / prims_tested counted by the    */
     uint64_t prims_tested_primary;  /* depth-0 (camera ray) launches; only when collect_stats  */
     /* ---- ABI v2 ---- */
-    uint64_t bounce_segments;      /* segments of the stand-alone bounce traversal launches (k_walk: the dominant kernel) */
+    uint64_t bounce_segments;      /* segments of the first-bounce traversal launches (k_walk on the depth-1 queue, one
+                                      launch per pass: the dominant kernel)                    */
     double seconds_trace_bounce;   /* their event-timed duration (part of seconds_trace)       */
     uint64_t bounce_launches;
-    uint64_t tail_segments;        /* segments traced AND shaded inside the persistent tail kernel (depth >= 2) */
-    double seconds_tail;           /* its event-timed duration                                 */
+    uint64_t tail_segments;        /* segments from depth 2 on: the stand-alone k_walk + k_shade pairs of the next few
+                                      depths and the persistent trace-and-shade kernel that takes the rest */
+    double seconds_tail;           /* event-timed duration of all of that                      */
     uint64_t nodes_visited_bounce, prims_tested_bounce;   /* collect_stats: the stand-alone bounce launches alone */
     uint64_t wave_node_fetches_primary;  /* collect_stats: node / primitive records the coherent camera-ray kernel  */
     uint64_t wave_prim_fetches_primary;  /* fetched once per WAVE (its memory traffic; the *_primary counts are per lane) */

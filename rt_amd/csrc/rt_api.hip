@@ -463,7 +463,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     }
     const double t0 = now_s();
 
-    // event timings of the pass a pipe has finished (phases: camera rays | first-bounce traversal | shading | tail | sums)
+    // event timings of the pass a pipe has finished (phases: camera rays | first-bounce traversal | its shading | every
+    // deeper bounce: stand-alone pairs, then the persistent kernel | sums)
     auto collect = [&](Pipe& P) -> int {
         if (!P.in_flight) return RT_OK;
         Workspace& w = *P.w;
@@ -515,6 +516,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         unsigned long long* sg_primary = w.stat_counters + STAT_GROUP * STAT_GROUP_PRIMARY;
         unsigned long long* sg_bounce = w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE;
         unsigned long long* sg_tail = w.stat_counters + STAT_GROUP * STAT_GROUP_TAIL;
+        unsigned long long* sg_deep = w.stat_counters + STAT_GROUP * STAT_GROUP_DEEP;
 
         // Ramp: the first pass of every pipe starts when the pass before it has traced its camera rays, so that the pipes
         // run out of phase (the coherent camera rays of one pass share the GPU with the incoherent bounces of another);
@@ -555,9 +557,9 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const uint32_t tail_depth = tail_depth_now();
         for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_bounce, ws, estimate(depth, n));
+            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, depth == 1 ? sg_bounce : sg_deep, ws, estimate(depth, n));
             st.trace_launches++;
-            st.bounce_launches++;
+            if (depth == 1) st.bounce_launches++;
             if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], ws)); ev2 = true; }
             if ((rc = to_side())) return rc;
             if (depth >= 2) HIPCHK(hipMemsetAsync(cnt[cset ^ 1], 0, COUNTER_BYTES, ws));      // (set last read two kernels ago)
@@ -565,12 +567,13 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             launch_shade(sc->d, pp, depth, w.q[cur], qg, n, est, w.hb, w.q[cur ^ 1], cnt[cset ^ 1], w.path_radiance,
                          depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, ws);
             st.launches += est && est < n ? 3 : 2;
+            if (depth == 1) HIPCHK(hipEventRecord(w.ev[3], ws));
             cur ^= 1;
             cset ^= 1;
         }
         if (!ev2) HIPCHK(hipEventRecord(w.ev[2], ws));
         if ((rc = to_side())) return rc;
-        HIPCHK(hipEventRecord(w.ev[3], ws));
+        if (depth == 1) HIPCHK(hipEventRecord(w.ev[3], ws));      // (no stand-alone pair ran)
         // ---- every remaining bounce inside one persistent launch
         if (depth <= cam->max_depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
@@ -616,12 +619,13 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const unsigned long long* hp = h + STAT_GROUP * STAT_GROUP_PRIMARY;
         const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
         const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
+        const unsigned long long* hd = h + STAT_GROUP * STAT_GROUP_DEEP;
         st.bounce_segments += hb_[STAT_SEGMENTS];
-        st.tail_segments += ht[STAT_SEGMENTS];
-        st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS];
+        st.tail_segments += ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
+        st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
         if (want_stats) {
-            st.nodes_visited += hp[STAT_NODES] + hb_[STAT_NODES] + ht[STAT_NODES];
-            st.prims_tested += hp[STAT_PRIMS] + hb_[STAT_PRIMS] + ht[STAT_PRIMS];
+            st.nodes_visited += hp[STAT_NODES] + hb_[STAT_NODES] + ht[STAT_NODES] + hd[STAT_NODES];
+            st.prims_tested += hp[STAT_PRIMS] + hb_[STAT_PRIMS] + ht[STAT_PRIMS] + hd[STAT_PRIMS];
             st.nodes_visited_primary += hp[STAT_NODES];
             st.prims_tested_primary += hp[STAT_PRIMS];
             st.nodes_visited_bounce += hb_[STAT_NODES];

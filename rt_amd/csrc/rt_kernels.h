@@ -42,7 +42,8 @@ void finish_pass_params(PassParams& pp);
 
 // ---- device statistics: groups of STAT_GROUP u64 counters, one group per kind of launch ----------
 constexpr int STAT_GROUP = 16;
-enum { STAT_GROUP_PRIMARY = 0, STAT_GROUP_BOUNCE = 1, STAT_GROUP_TAIL = 2, STAT_GROUPS = 3 };
+enum { STAT_GROUP_PRIMARY = 0, STAT_GROUP_BOUNCE = 1 /* first-bounce traversal */, STAT_GROUP_TAIL = 2 /* persistent kernel */,
+       STAT_GROUP_DEEP = 3 /* stand-alone traversal launches from depth 2 on */, STAT_GROUPS = 4 };
 enum {
     STAT_NODES = 0,        // nodes visited, per lane          (collect_stats)
     STAT_PRIMS = 1,        // primitives tested, per lane      (collect_stats)
