@@ -11,7 +11,14 @@ the dump record by record.
   cargo run --release --example dump_hits -- scene.rthx hits.rthd      # in the reference checkout
   python -m rt_amd.hits_exchange compare scene.rthx hits.rthd          # needs the GPU library
 
-Formats are little-endian and documented in dump_hits.rs.  The rays are the un-jittered pixel-centre rays of the
+With `integration/rust/patches/rt-counter-rng.patch` applied to the reference (its six thread_rng() draws become
+slots of the Philox counter this library uses), `integration/rust/dump_render.rs` dumps a whole render and
+
+  python -m rt_amd.hits_exchange compare-render scene.rthx render.rtrd  # needs the GPU library
+
+renders the same scene, camera, seed and sky state through `rt_render` and compares the per-pixel means.
+
+Formats are little-endian and documented in dump_hits.rs / dump_render.rs.  The rays are the un-jittered pixel-centre rays of the
 scene's camera (`Camera::debug_ray`, src/camera.rs:256-260), un-normalised as the reference hands them to Ray::new.
 """
 import struct
@@ -23,6 +30,7 @@ from . import _abi
 
 MAGIC_X = b"RTHX0001"
 MAGIC_D = b"RTHD0001"
+MAGIC_R = b"RTRD0001"
 dump_dt = np.dtype([("prim", "<u4"), ("_pad", "<u4"), ("t_bits", "<u8")])
 
 
@@ -95,7 +103,58 @@ def read_dump(path):
     return np.frombuffer(buf, dump_dt, n, 16)
 
 
-def desc_from_exchange(ex):
+def write_render_dump(path, image, spp, max_depth, seed, camera12, sky):
+    """image (H, W, 3) f64; camera12 = center, lookat, up, vfov, focus_distance, defocus_angle; sky = sky_dt record."""
+    h, w, _ = image.shape
+    with open(path, "wb") as f:
+        f.write(MAGIC_R)
+        f.write(struct.pack("<IIIIQ", w, h, spp, max_depth, seed))
+        f.write(np.asarray(camera12, "<f8").tobytes())
+        f.write(np.asarray(sky["params"], "<f4").reshape(27).tobytes())
+        f.write(np.asarray(sky["radiances"], "<f4").reshape(3).tobytes())
+        f.write(np.asarray(sky["sun"], "<f8").reshape(3).tobytes())
+        f.write(np.ascontiguousarray(image, "<f8").tobytes())
+
+
+def read_render_dump(path):
+    """-> dict(width, height, spp, max_depth, seed, camera (12,), sky (sky_dt record), image (H, W, 3))"""
+    with open(path, "rb") as f:
+        buf = f.read()
+    if buf[:8] != MAGIC_R:
+        raise ValueError("not an RTRD0001 file")
+    w, h, spp, depth, seed = struct.unpack_from("<IIIIQ", buf, 8)
+    off = 8 + 24
+    if len(buf) != off + 96 + 120 + 24 + 24 * w * h:
+        raise ValueError("RTRD0001 file has the wrong length")
+    cam = np.frombuffer(buf, "<f8", 12, off)
+    sky = _abi.one(_abi.sky_dt)
+    sky["params"] = np.frombuffer(buf, "<f4", 27, off + 96)
+    sky["radiances"] = np.frombuffer(buf, "<f4", 3, off + 96 + 108)
+    sky["sun"] = np.frombuffer(buf, "<f8", 3, off + 96 + 120)
+    image = np.frombuffer(buf, "<f8", 3 * w * h, off + 96 + 120 + 24).reshape(h, w, 3)
+    return {"width": w, "height": h, "spp": spp, "max_depth": depth, "seed": seed, "camera": cam, "sky": sky,
+            "image": image}
+
+
+def camera_from_render_dump(rd):
+    from . import api
+    c = rd["camera"]
+    return api.Camera.new(tuple(c[0:3]), tuple(c[3:6]), tuple(c[6:9]), float(c[10]), float(c[11]), rd["width"],
+                          rd["height"], rd["spp"], rd["max_depth"], float(c[9]))
+
+
+def compare_renders(ours, theirs, rtol=1e-9):
+    """-> (n_values, n_bit_identical, indices beyond rtol).  The reference sums a pixel's samples with rayon's
+    `.sum()`, whose association order is free, so only spp == 1 is expected to be bit-identical."""
+    a, b = np.ascontiguousarray(ours, "<f8").ravel(), np.ascontiguousarray(theirs, "<f8").ravel()
+    if a.shape != b.shape:
+        raise ValueError(f"image sizes differ: {a.shape} vs {b.shape}")
+    same = int(np.count_nonzero(a.view("<u8") == b.view("<u8")))
+    bad = np.nonzero(~(np.abs(a - b) <= rtol * np.maximum(np.abs(a), np.abs(b))))[0]
+    return a.size, same, bad
+
+
+def desc_from_exchange(ex, sky=None):
     """SceneDesc of the exchange file's shapes (one grey Lambertian; normals as Triangle::new computes them)."""
     from . import api
     mat = api.Lambertian.new_rgb_solid(0.5, 0.5, 0.5)
@@ -106,7 +165,7 @@ def desc_from_exchange(ex):
         from .importers import TriangleSoup
         soup = TriangleSoup(t[:, 0:3].copy(), t[:, 3:6].copy(), t[:, 6:9].copy(), mat, t[:, 9:15].reshape(-1, 3, 2).copy())
         shapes.append(soup)
-    return api.SceneDesc.from_shapes(shapes)
+    return api.SceneDesc.from_shapes(shapes, sky)
 
 
 def compare_dumps(ours, theirs):
@@ -146,6 +205,18 @@ def _main(argv):
             print(f"  ray {i}: library (prim {ours['prim'][i]}, t bits {ours['t_bits'][i]:#018x})  "
                   f"reference (prim {theirs['prim'][i]}, t bits {theirs['t_bits'][i]:#018x})")
         return 0 if len(bad) == len(ties) else 1
+    if len(argv) == 4 and argv[1] == "compare-render":
+        from . import api
+        ex = read_exchange(argv[2])
+        rd = read_render_dump(argv[3])
+        world = api.World.build(desc_from_exchange(ex, rd["sky"]))
+        ours = camera_from_render_dump(rd).render_image(world, spp=rd["spp"], seed=rd["seed"])
+        n, same, bad = compare_renders(ours, rd["image"])
+        print(f"{n} values at {rd['spp']} spp: {same} bit-identical, {len(bad)} beyond rtol 1e-9")
+        for i in bad[:10]:
+            print(f"  value {i} (pixel {i // 3}, channel {i % 3}): library {ours.ravel()[i]!r}  reference "
+                  f"{rd['image'].ravel()[i]!r}")
+        return 0 if len(bad) == 0 and (rd["spp"] != 1 or same == n) else 1
     print(__doc__)
     return 2
 

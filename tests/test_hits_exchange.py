@@ -61,3 +61,78 @@ def test_compare_command_against_library(tmp_path, capsys):
     hx.write_dump(d, OracleScene(hx.desc_from_exchange(ex)).hit(ex["rays"], ex["t_min"], ex["t_max"], mode=BVH_PRUNE))
     assert hx._main(["hits_exchange", "compare", str(x), str(d)]) == 0
     assert f"{160 * 90} rays: {160 * 90} identical" in capsys.readouterr().out
+
+
+def test_render_dump_round_trip_and_compare(tmp_path):
+    """RTRD0001 (integration/rust/dump_render.rs): the header rebuilds the very same camera and sky records, the
+    image round-trips, and the comparison separates bit-identical values from values beyond the tolerance."""
+    cam12 = (13.0, 2.0, 3.0, 0.0, 0.5, 0.0, 0.0, 1.0, 0.0, 20.0, 10.0, 0.6)
+    sky = scenes.cover_scene().sky
+    img = np.random.default_rng(3).random((9, 16, 3))
+    p = tmp_path / "r.rtrd"
+    hx.write_render_dump(p, img, 4, 7, 99, cam12, sky)
+    rd = hx.read_render_dump(p)
+    assert (rd["width"], rd["height"], rd["spp"], rd["max_depth"], rd["seed"]) == (16, 9, 4, 7, 99)
+    np.testing.assert_array_equal(rd["image"], img)
+    assert rd["sky"].tobytes() == np.asarray(sky).tobytes()
+    from rt_amd import api
+    want = api.Camera.new(cam12[0:3], cam12[3:6], cam12[6:9], 10.0, 0.6, 16, 9, 4, 7, 20.0)
+    assert hx.camera_from_render_dump(rd).rec.tobytes() == want.rec.tobytes()
+
+    n, same, bad = hx.compare_renders(img, rd["image"])
+    assert (n, same, len(bad)) == (16 * 9 * 3, 16 * 9 * 3, 0)
+    other = img.copy()
+    other[2, 3, 1] *= 1.0 + 4e-16                          # an ulp or two: inside the tolerance, not bit-identical
+    other[4, 5, 2] *= 1.0 + 1e-6
+    n, same, bad = hx.compare_renders(img, other)
+    assert same == n - 2 and list(bad) == [(4 * 16 + 5) * 3 + 2]
+    with open(p, "r+b") as f:
+        f.truncate(1000)
+    with pytest.raises(ValueError):
+        hx.read_render_dump(p)
+
+
+def test_rust_binding_source_covers_the_abi():
+    """integration/rust/rt-hip-sys is source only (no cargo here): check as text that it declares every exported
+    symbol, asserts the struct sizes the ctypes mirror asserts, and carries the ABI version of the header."""
+    import os
+    import re
+    from rt_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "integration/rust/rt-hip-sys/src/lib.rs")).read()
+    declared = set(re.findall(r"pub fn (rt_\w+)\(", src))
+    assert declared == set(_lib.EXPORTS)
+    header = open(os.path.join(root, "include/rt_hip.h")).read()
+    version = re.search(r"#define RT_ABI_VERSION (\d+)u", header).group(1)
+    assert f"RT_ABI_VERSION: u32 = {version};" in src
+    sizes = dict(re.findall(r"size_of::<Rt(\w+)>\(\) == (\d+)", src))
+    rust_name = {"rt_sphere": "Sphere", "rt_triangle": "Triangle", "rt_material": "Material", "rt_texture": "Texture",
+                 "rt_sky": "Sky", "rt_camera": "Camera", "rt_opts": "Opts", "rt_stats": "Stats", "rt_ray": "Ray",
+                 "rt_hit": "Hit", "rt_scene_info": "SceneInfo"}
+    for c_name, (dt, size) in _abi.EXPECTED_SIZES.items():
+        assert int(sizes[rust_name[c_name]]) == size == dt.itemsize, c_name
+    patch = open(os.path.join(root, "integration/rust/patches/rt-counter-rng.patch")).read()
+    removed = [l for l in patch.splitlines() if l.startswith("-") and "thread_rng()" in l]
+    assert len(removed) == 6                               # camera.rs:288, :369; material.rs:98, :112, :164, :170
+
+
+@pytest.mark.gpu
+def test_compare_render_command_against_library(tmp_path, capsys):
+    """`python -m rt_amd.hits_exchange compare-render` end to end; the oracle's render stands in for the patched
+    reference's dump (no cargo in the image), so this pins the tool, not the reference."""
+    desc = scenes.cover_scene()
+    x, d = tmp_path / "cover.rthx", tmp_path / "cover.rtrd"
+    cam12 = (13.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 20.0, 10.0, 0.0)
+    w, h, depth, seed = 64, 36, 6, 5
+    from rt_amd import api
+    for spp in (1, 3):
+        cam = api.Camera.new(cam12[0:3], cam12[3:6], cam12[6:9], 10.0, 0.0, w, h, spp, depth, 20.0)
+        hx.write_exchange(x, desc, hx.pixel_centre_rays(cam)[:1], 0.001, float(cam.rec["t_max"][0]))
+        back = hx.desc_from_exchange(hx.read_exchange(x), desc.sky)
+        img = OracleScene(back).render(cam, spp, seed=seed)
+        hx.write_render_dump(d, np.asarray(img).reshape(h, w, 3), spp, depth, seed, cam12, desc.sky)
+        assert hx._main(["hits_exchange", "compare-render", str(x), str(d)]) == 0
+        out = capsys.readouterr().out
+        assert "0 beyond rtol" in out
+        if spp == 1:
+            assert f"{w * h * 3} bit-identical" in out
