@@ -8,8 +8,8 @@
 //! then, on a machine with the library built,
 //!     python -m rt_amd.hits_exchange compare-render scene.rthx render.rtrd
 //! which renders the same scene, camera, seed and sky state through `rt_render` and compares the mean radiance
-//! per pixel.  Additions in the reference are a rayon `.sum()` (src/camera.rs:323), whose association order is not
-//! fixed, so the comparison is to rtol 1e-9 and not bit-exact; with SPP = 1 it IS bit-exact and the tool says so.
+//! per pixel to rtol 2e-6: the sky's f32 cos/exp/pow come from different math libraries on the two sides, and the
+//! reference adds a pixel's samples with a rayon `.sum()` (src/camera.rs:323), whose association order is not fixed.
 //!
 //! Scene: the shapes of the .rthx file (formats in dump_hits.rs) with one grey Lambertian (0.5, 0.5, 0.5) — the same
 //! stand-in `hits_exchange.desc_from_exchange` builds.  The sky is the reference's own: `World::build` makes the

@@ -83,13 +83,19 @@ double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t dept
     return (double)(bits >> 11) * 0x1.0p-53;
 }
 
+/* Slot table of a path vertex (depth = bounce index).  SURVEY.md App. C with slots 0 and 4 exchanged, so that the four
+ * draws of a Lambertian vertex (roulette + random_unit) sit in two Philox blocks instead of three; the slots are
+ * independent uniforms, so nothing else changes.  integration/rust/patches/rt-counter-rng.patch uses the same table. */
+#define SLOT_ROULETTE 0u      /* russian_roulette: survive iff u < p        (src/camera.rs:288) */
+#define SLOT_UNIT 1u          /* 1, 2, 3: Vec3::random_unit                 (src/vec3.rs:113-120) */
+#define SLOT_NOISE 4u         /* Dielectric reflect-or-refract noise       (src/material.rs:164) */
 typedef struct { uint64_t seed; uint32_t pixel, sample, depth; } rng_key;
 static inline double rng_u(const rng_key* k, uint32_t slot) {
     return orc_uniform(k->seed, k->pixel, k->sample, k->depth, slot);
 }
 /* Vec3::random(-1,1).normalize() (src/vec3.rs:113-120) on slots 1,2,3 */
 static inline v3 random_unit(const rng_key* k) {
-    v3 r = V(2.0 * rng_u(k, 1) - 1.0, 2.0 * rng_u(k, 2) - 1.0, 2.0 * rng_u(k, 3) - 1.0);
+    v3 r = V(2.0 * rng_u(k, SLOT_UNIT) - 1.0, 2.0 * rng_u(k, SLOT_UNIT + 1) - 1.0, 2.0 * rng_u(k, SLOT_UNIT + 2) - 1.0);
     return vnormalize(r);
 }
 
@@ -516,7 +522,7 @@ static void scatter(const orc_scene* S, const ray_t* rin, const isect* h, const 
         double c = fmin(-vdot(din, h->normal), 1.0);
         double s = sqrt(1.0 - c * c);
         int cannot = ri * s > 1.0;
-        double noise = rng_u(k, 0);
+        double noise = rng_u(k, SLOT_NOISE);
         v3 dir;
         if (cannot || reflectance(c, ri) > noise) dir = reflect(din, h->normal);
         else if (m->has_fuzz) dir = vadd(refract(din, h->normal, ri), vscale(random_unit(k), m->fuzz));
@@ -607,7 +613,7 @@ static v3 raycast(tracer* T, const ray_t* r, uint32_t depth, uint32_t pixel, uin
         scatter(T->S, r, &h, &k, &att, &sc);
         if (depth < T->cam->max_depth) {
             double p = fmax(fmax(att.x, att.y), att.z);             /* Vector3::max() */
-            if (rng_u(&k, 4) < p) {                                  /* gen_bool(p) */
+            if (rng_u(&k, SLOT_ROULETTE) < p) {                      /* gen_bool(p) */
                 v3 w = vdivs(vscale(att, 1.0), p);                   /* ray_color * 1.0 / p */
                 v3 bounced = raycast(T, &sc, depth + 1, pixel, sample);
                 return vmul(w, bounced);

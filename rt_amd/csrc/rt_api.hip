@@ -141,6 +141,7 @@ struct Workspace {
     uint32_t* h_hist = nullptr;                    // pinned copy, read when the pipe is reused (launch estimates only)
     double* jitter = nullptr;                      // Halton table of the pass in flight (2 doubles per local sample)
     size_t jitter_cap = 0;                         // in samples
+    StackOverflow ovf = {nullptr, 0u, 0u};         // traversal-stack rows beyond the LDS part (deep trees only)
     unsigned long long* stat_counters = nullptr;   // STAT_GROUPS groups of STAT_GROUP u64
     unsigned long long* h_stat = nullptr;          // pinned copy of them
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the pass in flight
@@ -179,6 +180,7 @@ void free_workspace(Workspace& w) {
     if (w.h_stat) (void)hipHostFree(w.h_stat);
     if (w.h_hist) (void)hipHostFree(w.h_hist);
     if (w.jitter) (void)hipFree(w.jitter);
+    if (w.ovf.rows) (void)hipFree(w.ovf.rows);
     for (auto& e : w.ev)
         if (e) (void)hipEventDestroy(e);
     w = Workspace();
@@ -200,6 +202,19 @@ int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
         HIPCHK(hipHostMalloc((void**)&w.h_hist, HIST_BYTES, hipHostMallocDefault));
         memset(w.h_hist, 0, HIST_BYTES);
         for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
+    }
+    // deep trees: the rows of the traversal stack beyond its LDS part, a column per lane of a persistent launch
+    // (16 waves per CU is what the registers of the traversal kernel allow at most)
+    const uint32_t ovf_rows = stack_overflow_rows(sc->d);
+    if (ovf_rows > w.ovf.rows_cap) {
+        if (w.ovf.rows) (void)hipFree(w.ovf.rows);
+        w.ovf = {nullptr, 0u, 0u};
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, sc->device));
+        const uint32_t waves = (uint32_t)pr.multiProcessorCount * 16u;
+        uint32_t* rows = nullptr;
+        if (hipMalloc((void**)&rows, (size_t)ovf_rows * waves * 64u * sizeof(uint32_t)) == hipSuccess) w.ovf = {rows, ovf_rows, waves};
+        else (void)hipGetLastError();              // not fatal: the kernels then keep the whole stack in LDS
     }
     if (paths <= w.capacity) return RT_OK;
     if (w.base) {
@@ -532,7 +547,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.launches++;
         } else {
             launch_raygen(pp, dense, w.q[0], P.s);
-            launch_walk(sc->d, w.q[0], dense, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s);
+            launch_walk(sc->d, w.q[0], dense, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s, 0, &w.ovf);
             st.launches += 2;
         }
         if (!fuse_shade) {
@@ -557,7 +572,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const uint32_t tail_depth = tail_depth_now();
         for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, depth == 1 ? sg_bounce : sg_deep, ws, estimate(depth, n));
+            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, depth == 1 ? sg_bounce : sg_deep, ws, estimate(depth, n), &w.ovf);
             st.trace_launches++;
             if (depth == 1) st.bounce_launches++;
             if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], ws)); ev2 = true; }
@@ -578,7 +593,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         if (depth <= cam->max_depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
             launch_walk_shade(sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance,
-                              depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, want_stats, sg_tail, ws, estimate(depth, n));
+                              depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, want_stats, sg_tail, ws, estimate(depth, n), &w.ovf);
             st.launches++;
         }
         HIPCHK(hipMemcpyAsync(w.h_hist, w.hist, HIST_DEPTHS * sizeof(uint32_t), hipMemcpyDeviceToHost, ws));
@@ -1148,7 +1163,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
         const QueueGeom qg = {nullptr, shard_cap_for(m), m};
         launch_prepare_rays(d_rays, qg, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_walk(sc->d, w.q[0], qg, m, t_min, t_max, w.hb, want_stats, want_stats ? sg : nullptr, stream);
+        launch_walk(sc->d, w.q[0], qg, m, t_min, t_max, w.hb, want_stats, want_stats ? sg : nullptr, stream, 0, &w.ovf);
         HIPCHK(hipEventRecord(w.ev[1], stream));
         launch_pack_hits(w.hb, qg, d_hits, stream);
         HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -1254,7 +1269,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     if (getenv("RT_HIP_PRIMARY_PACKET") && packet_supported(sc->d))
         launch_trace_packet(sc->d, nullptr, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, nullptr);
     else
-        launch_walk(sc->d, w.q[0], qm, (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, nullptr, stream);
+        launch_walk(sc->d, w.q[0], qm, (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, 0, &w.ovf);
     launch_pack_hits(w.hb, qm, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {

@@ -398,7 +398,10 @@ __device__ __forceinline__ float sky_radiance(const rt_sky& sky, float theta, fl
     float exp_m = expf(p[4] * gamma);
     float ray_m = cos_gamma2;
     float mie_m_lhs = 1.0f + cos_gamma2;
-    float mie_m_rhs = powf(1.0f + p[8] * p[8] - 2.0f * p[8] * cos_gamma, 1.5f);
+    // powf(b, 1.5): b * sqrt(b) is within 1.5 ulp of it (sqrt is correctly rounded; NaN for b < 0, 0 and inf kept) and a tenth
+    // of OCML powf's ~150 instructions — the sky is evaluated once for nearly every path, three channels each
+    const float mie_b = 1.0f + p[8] * p[8] - 2.0f * p[8] * cos_gamma;
+    float mie_m_rhs = mie_b * sqrtf(mie_b);
     float mie_m = mie_m_lhs / mie_m_rhs;
     float zenith = sqrtf(cos_theta);
     float radiance_lhs = 1.0f + p[0] * expf(p[1] / (cos_theta + 0.01f));

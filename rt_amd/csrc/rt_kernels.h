@@ -65,13 +65,22 @@ void launch_prepare_rays(const rt_ray* rays, const QueueGeom& qg, RayQueue q, hi
 // (it only sizes the launch; the kernel reads the queue's counts from device memory).  d_counters: one statistics
 // group, or NULL.
 // n_estimate (0 = none): the entry count the host expects; sizes the persistent grid (any real count is still served).
+// ovf (may be NULL): device rows for the part of the per-lane traversal stack that does not fit the 32 LDS rows the
+// kernels keep when the tree needs more (stack_overflow_rows(S) > 0): rows_cap rows of waves * 64 entries.  Without it
+// such trees are walked with the whole stack in LDS (fewer waves per CU).
+struct StackOverflow {
+    uint32_t* rows;
+    uint32_t rows_cap;     // rows available
+    uint32_t waves;        // columns available / 64: the persistent launch never has more waves than this
+};
+uint32_t stack_overflow_rows(const DScene& S);       // rows a StackOverflow buffer needs for this scene (0: none)
 void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
-                 bool stats, unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0);
+                 bool stats, unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0, const StackOverflow* ovf = nullptr);
 // K1 + K2-4, persistent: traces AND shades the queue's paths (entries at depth depth0), bounce after bounce inside
 // the kernel, until every path has ended (radiance slots written)
 void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
                        double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
-                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0);
+                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0, const StackOverflow* ovf = nullptr);
 // K1p: closest hit for coherent waves (camera rays; always a dense queue): wave-level packet traversal through the scalar cache
 // gen != NULL: the kernel generates the camera rays of that pass itself (K0 fused) and stores them in q
 // fuse != NULL (needs gen): the kernel also shades depth 0 and appends the survivors to fuse->q_out (the launch

@@ -284,8 +284,15 @@ struct WalkShade {
     uint32_t _pad;
     double* path_radiance;
     uint32_t* hist;             // may be null
+    uint32_t* stack_ovf;        // OVF kernels: stack rows beyond OVF_LDS_ROWS, [row][launched lane]
 };
-template <class BoxT, int WIDTH, bool STATS, bool SHADE>
+// OVF: the LDS stack holds OVF_LDS_ROWS entries per lane whatever the tree's worst case is, and deeper entries go to a
+// per-lane column in device memory.  A wave's LDS decides how many waves a CU holds: 48 or 64 rows (trees of 5 M+
+// triangles) leave 2.5-3 waves per SIMD where the registers allow 4, and these walks are bound by memory latency, i.e. by
+// the number of waves in flight.  Real traversals stay far below the worst case the builder computes, so the overflow
+// rows are touched by few lanes.
+constexpr uint32_t OVF_LDS_ROWS = 32;
+template <class BoxT, int WIDTH, bool STATS, bool SHADE, bool OVF>
 __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, const QueueGeom qg, double t_min, double t_max,
                                           const HitBuf hb, unsigned long long* counters, const WalkShade sh) {
     // (by VALUE on purpose: through references the compiler turned the base-pointer select of the fetch below into a
@@ -293,6 +300,13 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
     extern __shared__ uint32_t stack_mem[];
     uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
     const uint32_t tid = threadIdx.x;
+    // (the overflow address is formed where it is used: a per-lane pointer kept across the loop would cost the kernel the
+    // two registers that decide whether a camera-ray or shading wave still fits next to four of its waves on a SIMD)
+#define RT_OVF_AT(row) sh.stack_ovf[((uint32_t)(row) * gridDim.x + blockIdx.x) * (uint32_t)TRACE_BLOCK + tid]      // (< 2^32: the launcher checks)
+    // `deep` (wave-uniform, set once per step): some lane's stack may reach the overflow rows in this step; otherwise the
+    // pushes and pops are the plain LDS ones — one compare and one scalar branch per step instead of a check per access
+#define RT_PUSH(v) { if (!OVF || !deep || (uint32_t)sp < OVF_LDS_ROWS) stack[sp][tid] = (v); else RT_OVF_AT((uint32_t)sp - OVF_LDS_ROWS) = (v); ++sp; }
+#define RT_POP() (--sp, (!OVF || !deep || (uint32_t)sp < OVF_LDS_ROWS) ? stack[sp][tid] : RT_OVF_AT((uint32_t)sp - OVF_LDS_ROWS))
     // The queue's counts are read once here (size in waves, total) and looked up again per refill through the scalar
     // cache (slot_light): nothing of them stays in a VGPR across the loop — the kernel's register count decides whether
     // a camera-ray or shading wave of another pass still fits next to four of its waves on a SIMD.
@@ -397,6 +411,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             continue;
         }
         if (STATS) ++n_iters;
+        const bool deep = OVF && __ballot((uint32_t)sp > OVF_LDS_ROWS - 3u) != 0ull;
         // One dependent memory round trip per iteration for every lane: a node lane fetches its 64-byte node,
         // a leaf lane ONE primitive of its leaf (80-byte triangle / 64-byte sphere); a leaf of n primitives
         // takes n iterations (the reference keeps count and first, so it is advanced in place).  All loads are
@@ -459,10 +474,10 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                       const uint32_t rx = sw ? ref[y] : ref[x], ry = sw ? ref[x] : ref[y]; key[x] = kx; key[y] = ky; ref[x] = rx; ref[y] = ry; }
                 RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-                if (ref[3] != REF_EMPTY) stack[sp++][tid] = ref[3];
-                if (ref[2] != REF_EMPTY) stack[sp++][tid] = ref[2];
-                if (ref[1] != REF_EMPTY) stack[sp++][tid] = ref[1];
-                cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? stack[--sp][tid] : REF_EMPTY);
+                if (ref[3] != REF_EMPTY) RT_PUSH(ref[3])
+                if (ref[2] != REF_EMPTY) RT_PUSH(ref[2])
+                if (ref[1] != REF_EMPTY) RT_PUSH(ref[1])
+                cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? RT_POP() : REF_EMPTY);
             } else {
                 typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
                 uint32_t cl, cr;
@@ -471,14 +486,14 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 const bool hr = cr != REF_EMPTY && rb.test(lo_r, hi_r, tr);
                 if (hl && hr) {
                     const bool left_first = tl <= tr;
-                    stack[sp++][tid] = left_first ? cr : cl;
+                    RT_PUSH(left_first ? cr : cl)
                     cur = left_first ? cl : cr;
                 } else if (hl) {
                     cur = cl;
                 } else if (hr) {
                     cur = cr;
                 } else {
-                    cur = sp ? stack[--sp][tid] : REF_EMPTY;
+                    cur = sp ? RT_POP() : REF_EMPTY;
                 }
             }
         }
@@ -505,13 +520,16 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
             }
             // next primitive of the same leaf, or pop
-            cur = (cur & 0x30000000u) ? cur - 0x10000000u + 1u : (sp ? stack[--sp][tid] : REF_EMPTY);
+            cur = (cur & 0x30000000u) ? cur - 0x10000000u + 1u : (sp ? RT_POP() : REF_EMPTY);
         }
 #ifdef RT_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RT_STAMP(tm_prim)
 #endif
     }
+#undef RT_PUSH
+#undef RT_POP
+#undef RT_OVF_AT
     if (SHADE && counters) {
         unsigned long long sg = n_seg;
         for (int off = 32; off; off >>= 1) sg += __shfl_xor(sg, off);
@@ -542,20 +560,20 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
 // k_walk_shade is the persistent trace-and-shade kernel.  Separate __global__ functions so that each has its own
 // register budget: RT_TAIL_WAVES caps k_walk_shade's (its shading code wants ~200 VGPRs; held by long-lived waves they
 // would keep the other passes' kernels out of the SIMDs).
-template <class BoxT, int WIDTH, bool STATS>
+template <class BoxT, int WIDTH, bool STATS, bool OVF>
 __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
                                                                        HitBuf hb, unsigned long long* counters, WalkShade sh) {
-    walk_body<BoxT, WIDTH, STATS, false>(S, q, qg, t_min, t_max, hb, counters, sh);
+    walk_body<BoxT, WIDTH, STATS, false, OVF>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
 #ifdef RT_TAIL_WAVES
 #define RT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(RT_TAIL_WAVES, RT_TAIL_WAVES)))
 #else
 #define RT_TAIL_ATTR
 #endif
-template <class BoxT, int WIDTH, bool STATS>
+template <class BoxT, int WIDTH, bool STATS, bool OVF>
 __global__ RT_TAIL_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk_shade(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
                                                                            HitBuf hb, unsigned long long* counters, WalkShade sh) {
-    walk_body<BoxT, WIDTH, STATS, true>(S, q, qg, t_min, t_max, hb, counters, sh);
+    walk_body<BoxT, WIDTH, STATS, true, OVF>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -791,7 +809,10 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
         const ShadeMat* m = &S.mats[h.material];
         const uint32_t kind = m->kind, has_fuzz = m->has_fuzz;
         RngKey key = {pp.seed, pixel, pp.sample_offset + (pp.pass_base + local) * pp.sample_stride, depth};
+        // Slots of a vertex: 0 roulette, 1-3 random_unit, 4 dielectric noise (Philox block b holds slots 2b, 2b+1): a
+        // Lambertian or fuzzy-metal vertex needs blocks 0 and 1, a plain metal block 0, a clear dielectric block 2 only.
         D3 att, dir;
+        U4 b0 = {0u, 0u, 0u, 0u};
         if (kind == RT_MAT_DIELECTRIC) {                        // src/material.rs:150-179
             double ior = m->ior;
             double ri = h.front ? 1.0 / ior : ior;
@@ -799,13 +820,14 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
             double c = fmin(-dot(din, h.n), 1.0);
             double sn = sqrt(1.0 - c * c);
             bool cannot = ri * sn > 1.0;
-            U4 b0 = rng_block(key, 0);
-            double noise = u64_to_unit(b0.x, b0.y);             // slot 0
+            U4 b2 = rng_block(key, 2);
+            double noise = u64_to_unit(b2.x, b2.y);             // slot 4
             if (cannot || reflectance(c, ri) > noise) {
                 dir = reflect(din, h.n);
             } else {
                 dir = refract(din, h.n, ri);
                 if (has_fuzz) {
+                    b0 = rng_block(key, 0);
                     U4 b1 = rng_block(key, 1);
                     D3 ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
                                          2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
@@ -816,8 +838,9 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
             att = mk(1.0, 1.0, 1.0);
         } else {
             D3 ru = mk(0, 0, 0);
+            b0 = rng_block(key, 0);
             if (kind == RT_MAT_LAMBERTIAN || has_fuzz) {        // Vec3::random_unit, slots 1,2,3 (src/vec3.rs:113-120)
-                U4 b0 = rng_block(key, 0), b1 = rng_block(key, 1);
+                U4 b1 = rng_block(key, 1);
                 ru = normalize(mk(2.0 * u64_to_unit(b0.z, b0.w) - 1.0, 2.0 * u64_to_unit(b1.x, b1.y) - 1.0,
                                   2.0 * u64_to_unit(b1.z, b1.w) - 1.0));
             }
@@ -833,8 +856,9 @@ __device__ __forceinline__ bool shade_path(const DScene& S, const PassParams& pp
         dir = normalize(dir);                                   // Ray::new(point, dir)
         if (depth < pp.cam.max_depth) {                         // src/camera.rs:300
             double p = fmax(fmax(att.x, att.y), att.z);         // russian_roulette (:280-293)
-            U4 b2 = rng_block(key, 2);
-            if (u64_to_unit(b2.x, b2.y) < p) {                  // slot 4
+            // slot 0; u < 1 whatever is drawn, so p >= 1 (every dielectric: att = ONE) needs no draw — and b0 is only
+            // missing for dielectrics that did not need random_unit
+            if (p >= 1.0 || u64_to_unit(b0.x, b0.y) < p) {
                 alive = true;
                 nthr = mul(thr, divs(scale(att, 1.0), p));
                 no = h.p;
@@ -1082,14 +1106,15 @@ static bool refill_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); retur
 static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
 
 // n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
-template <class BoxT, int WIDTH, bool STATS, bool SHADE>
+template <class BoxT, int WIDTH, bool STATS, bool SHADE, bool OVF>
 static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
-                          HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, hipStream_t s) {
+                          HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, uint32_t ovf_waves,
+                          hipStream_t s) {
     const size_t lds = (size_t)stack_entries * TRACE_BLOCK * sizeof(uint32_t);
     // the occupancy query is per (kernel instance, stack size); a handful of values occur
     static unsigned cached_slots[5] = {0, 0, 0, 0, 0};
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
-    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS>; else return k_walk<BoxT, WIDTH, STATS>; }();
+    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, OVF>; else return k_walk<BoxT, WIDTH, STATS, OVF>; }();
     if (!cached_slots[ci]) cached_slots[ci] = resident_waves(kernel, lds);
     const unsigned chunks = (n_upper + 63u) / 64u;
     // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks.
@@ -1104,55 +1129,80 @@ static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint
         static const int ts = getenv("RT_HIP_TAIL_SLOTS") ? atoi(getenv("RT_HIP_TAIL_SLOTS")) : 0;
         if (ts > 0) hw = (unsigned)ts;
     }
-    const unsigned slots = refill_enabled() ? std::min(refill_slots(hw), chunks) : chunks;
+    unsigned slots = refill_enabled() ? std::min(refill_slots(hw), chunks) : chunks;
+    if (OVF) slots = std::min<unsigned>(slots, ovf_waves);      // the overflow rows have one column per launched lane
     if (!slots) return;
     hipLaunchKernelGGL(kernel, dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
 }
 template <class BoxT, int WIDTH>
 static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
-                          HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+                          HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
+                          hipStream_t s) {
     // The per-lane stack needs S.stack4 entries for the BVH4 and one entry per level for the BVH2; a smaller stack means
     // less LDS per wave, i.e. more waves per CU.
     const uint32_t need = WIDTH == 4 ? S.stack4 : S.bvh_depth;
     const uint32_t entries = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : need <= 48 ? 48 : 64;
-    WalkShade none;
-    memset(&none, 0, sizeof(none));
+    WalkShade w;
+    if (sh) w = *sh; else memset(&w, 0, sizeof(w));
+    w.stack_ovf = nullptr;
+    if constexpr (WIDTH == 4) {
+        // deep trees: 32 rows in LDS, the rest in the caller's overflow buffer (persistent launches only: a column per launched lane)
+        if (need > OVF_LDS_ROWS && ovf.rows && need <= OVF_LDS_ROWS + ovf.rows_cap && ovf.waves && refill_enabled()) {
+            w.stack_ovf = ovf.rows;
+            if (sh) {
+                if (stats) launch_walk_k<BoxT, 4, true, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
+                else launch_walk_k<BoxT, 4, false, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
+            } else {
+                if (stats) launch_walk_k<BoxT, 4, true, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
+                else launch_walk_k<BoxT, 4, false, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
+            }
+            return;
+        }
+    }
     if (sh) {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, *sh, entries, s);
-        else launch_walk_k<BoxT, WIDTH, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, *sh, entries, s);
+        if (stats) launch_walk_k<BoxT, WIDTH, true, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
+        else launch_walk_k<BoxT, WIDTH, false, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
     } else {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, none, entries, s);
-        else launch_walk_k<BoxT, WIDTH, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, none, entries, s);
+        if (stats) launch_walk_k<BoxT, WIDTH, true, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
+        else launch_walk_k<BoxT, WIDTH, false, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
     }
 }
 static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
-                            HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, hipStream_t s) {
+                            HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
+                            hipStream_t s) {
     if (!n_upper) return;
     if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
-        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s); return; }
-        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s); return; }
+        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
+        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
     }
     if (S.nodes16)
-        launch_walk_b<Box16, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box16, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
     else if (S.nodes32)
-        launch_walk_b<Box32, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box32, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
     else
-        launch_walk_b<Box64, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, s);
+        launch_walk_b<Box64, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
+}
+uint32_t stack_overflow_rows(const DScene& S) {
+    static const bool off = getenv("RT_HIP_NO_STACK_OVF") && atoi(getenv("RT_HIP_NO_STACK_OVF")) == 1;
+    const bool w4 = S.stack4 <= (uint32_t)BVH4_MAX_STACK && (S.nodes4 || S.nodes4f);
+    return (!off && w4 && S.stack4 > OVF_LDS_ROWS) ? S.stack4 - OVF_LDS_ROWS : 0u;
 }
 void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb, bool stats,
-                 unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate) {
-    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, nullptr, s);
+                 unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {
+    StackOverflow none = {nullptr, 0u, 0u};
+    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, nullptr, ovf ? *ovf : none, s);
 }
 void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
                        double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
-                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate) {
+                       unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {
     WalkShade sh;
     memset(&sh, 0, sizeof(sh));
     sh.pp = pp;
     sh.depth0 = depth0;
     sh.path_radiance = d_path_radiance;
     sh.hist = d_hist;
-    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, &sh, s);
+    StackOverflow none = {nullptr, 0u, 0u};
+    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, &sh, ovf ? *ovf : none, s);
 }
 
 bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant

@@ -143,9 +143,11 @@ def camera_from_render_dump(rd):
                           rd["height"], rd["spp"], rd["max_depth"], float(c[9]))
 
 
-def compare_renders(ours, theirs, rtol=1e-9):
-    """-> (n_values, n_bit_identical, indices beyond rtol).  The reference sums a pixel's samples with rayon's
-    `.sum()`, whose association order is free, so only spp == 1 is expected to be bit-identical."""
+def compare_renders(ours, theirs, rtol=2e-6):
+    """-> (n_values, n_bit_identical, indices beyond rtol).  Not bit-exact by nature: the sky's f32 cos/exp/pow and the
+    f64 acos come from different math libraries (OCML here, the system libm under Rust: 1-2 ulp of f32, ~1e-7), the
+    throughput is multiplied forward here and on the way out of the recursion there, and rayon's `.sum()` has no fixed
+    association order.  2e-6 is the tolerance of every render comparison in tests/ (DESIGN.md §3)."""
     a, b = np.ascontiguousarray(ours, "<f8").ravel(), np.ascontiguousarray(theirs, "<f8").ravel()
     if a.shape != b.shape:
         raise ValueError(f"image sizes differ: {a.shape} vs {b.shape}")
@@ -212,11 +214,11 @@ def _main(argv):
         world = api.World.build(desc_from_exchange(ex, rd["sky"]))
         ours = camera_from_render_dump(rd).render_image(world, spp=rd["spp"], seed=rd["seed"])
         n, same, bad = compare_renders(ours, rd["image"])
-        print(f"{n} values at {rd['spp']} spp: {same} bit-identical, {len(bad)} beyond rtol 1e-9")
+        print(f"{n} values at {rd['spp']} spp: {same} bit-identical, {len(bad)} beyond rtol 2e-6")
         for i in bad[:10]:
             print(f"  value {i} (pixel {i // 3}, channel {i % 3}): library {ours.ravel()[i]!r}  reference "
                   f"{rd['image'].ravel()[i]!r}")
-        return 0 if len(bad) == 0 and (rd["spp"] != 1 or same == n) else 1
+        return 0 if len(bad) == 0 else 1
     print(__doc__)
     return 2
 

