@@ -1035,6 +1035,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             const bool force4 = nb && strcmp(nb, "w4") == 0;
             const bool force16 = (nb && strcmp(nb, "q16") == 0) || force4, no16 = nb && strcmp(nb, "f32") == 0;
             if (!no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
+                for (int k = 0; k < 3; ++k) sc->d.grid_inv_cell[k] = 1.0 / (double)sc->d.grid.cell[k];
                 if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
                 use16 = true;
                 std::vector<Node4> n4;

@@ -20,7 +20,22 @@ __device__ __forceinline__ D3 add(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, 
 __device__ __forceinline__ D3 sub(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ D3 mul(D3 a, D3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ D3 scale(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ D3 divs(D3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+// a / s for the three components with ONE reciprocal: y = RN(1/s), q0 = RN(a*y), r = a - s*q0 (exact, one fma),
+// q = RN(q0 + r*y).  With y within an ulp of 1/s, q0 + r*y is a/s to ~2^-104 relative, and a quotient of two doubles
+// is never that close to a rounding boundary without being exact, so q is the correctly rounded a / s — bit for bit
+// what three IEEE divisions give (it is the quotient step of the compiler's own division sequence; tests/native/
+// div_shared_check.c compares the two over 3e8 cases incl. significands of all ones).  20 instead of 33 f64
+// instructions per vector; a shaded vertex does three of these.  The form needs the remainder not to underflow and
+// y to be finite and non-zero: outside 2^-500 < |s| < 2^500 (never on the path: s is a vector length or a colour
+// component) the plain divisions are used; numerators below 2^-900 in magnitude other than 0 do not occur (directions
+// and colours), a zero numerator gives +0 where the division gives the numerator's sign.
+__device__ __forceinline__ D3 divs(D3 a, double s) {
+    const double m = fabs(s);
+    if (!(m > 0x1.0p-500 && m < 0x1.0p500)) return mk(a.x / s, a.y / s, a.z / s);
+    const double y = 1.0 / s;
+    const double qx = a.x * y, qy = a.y * y, qz = a.z * y;
+    return mk(fma(fma(-s, qx, a.x), y, qx), fma(fma(-s, qy, a.y), y, qy), fma(fma(-s, qz, a.z), y, qz));
+}
 __device__ __forceinline__ D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ double norm2(D3 a) { return dot(a, a); }

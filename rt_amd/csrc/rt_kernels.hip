@@ -202,10 +202,12 @@ struct Box16 : Box32 {
     uint32_t sx, sy, sz;
     __device__ __forceinline__ void init(const DScene& S, D3 o, D3 d, double t_min, double t_max) {
         lo_t = f32_below(t_min); hi_t = f32_above(t_max);
+        // (o - origin) * (1/cell) instead of a division: a relative 2^-52 on o', against the 2^-21 |K| the planes are
+        // widened by (budget above); three f64 divisions fewer per ray taken from the queue
         const double cx = (double)S.grid.cell[0], cy = (double)S.grid.cell[1], cz = (double)S.grid.cell[2];
-        set_axis((o.x - (double)S.grid.origin[0]) / cx, cx / d.x, ix, nx, fx);
-        set_axis((o.y - (double)S.grid.origin[1]) / cy, cy / d.y, iy, ny, fy);
-        set_axis((o.z - (double)S.grid.origin[2]) / cz, cz / d.z, iz, nz, fz);
+        set_axis((o.x - (double)S.grid.origin[0]) * S.grid_inv_cell[0], cx / d.x, ix, nx, fx);
+        set_axis((o.y - (double)S.grid.origin[1]) * S.grid_inv_cell[1], cy / d.y, iy, ny, fy);
+        set_axis((o.z - (double)S.grid.origin[2]) * S.grid_inv_cell[2], cz / d.z, iz, nz, fz);
         sx = ix < 0.f ? 0x01000706u : 0x07060100u;      // lo.x = w0[15:0],  hi.x = w1[31:16]   (perm(w1, w0))
         sy = iy < 0.f ? 0x03020504u : 0x05040302u;      // lo.y = w0[31:16], hi.y = w2[15:0]    (perm(w2, w0))
         sz = iz < 0.f ? 0x01000706u : 0x07060100u;      // lo.z = w1[15:0],  hi.z = w2[31:16]   (perm(w2, w1))

@@ -140,6 +140,7 @@ struct DScene {
     QuantGrid grid;              // of nodes16 and nodes4
     uint32_t stack4;             // traversal stack entries nodes4 / nodes4f need in the worst case
     uint32_t _pad2[1];
+    double grid_inv_cell[3];     // 1 / grid.cell (f64): a ray is moved into cell units with a multiplication
     rt_sky sky;
 };
 
