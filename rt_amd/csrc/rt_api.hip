@@ -279,7 +279,8 @@ bool finite3(const double* p) { return std::isfinite(p[0]) && std::isfinite(p[1]
 template <class T>
 int upload(rt_scene* sc, const std::vector<T>& v, const T** out) {
     void* p = nullptr;
-    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
+    // 256 bytes behind every array: the traversal kernels read up to 112 bytes from a record's address whatever its kind
+    size_t bytes = v.size() * sizeof(T) + 256;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1060,6 +1061,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                     if ((rc = upload(sc, n4f, &sc->d.nodes4f))) return rc;
                     sc->d.nodes4 = nullptr;
                     sc->d.stack4 = need;
+                    n_nodes4 = n4f.size();
                     use4 = true;
                     use4f = true;
                 }
@@ -1079,6 +1081,13 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->d.root = n_prims ? 0u : REF_EMPTY;
         sc->d.bvh_depth = bvh.depth;
         sc->d.sky = *sky;
+        {
+            // what the BVH4 walk touches: with it inside the 256 MB Infinity Cache the walk is bound by instruction issue and
+            // every lane fetches (walk_body); RT_HIP_ALL_LANES_LOAD=0|1 overrides
+            const size_t walked = n_nodes4 * (use4f ? sizeof(Node4f) : sizeof(Node4)) + n_triangles * sizeof(TriGeom) + n_spheres * sizeof(SphGeom);
+            const char* al = getenv("RT_HIP_ALL_LANES_LOAD");
+            sc->d.all_lanes_load = al ? (atoi(al) != 0) : (use4 && walked <= (size_t)256 << 20);
+        }
         HIPCHK(hipDeviceSynchronize());
         const double tb2 = now_s();
 

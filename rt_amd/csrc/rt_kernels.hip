@@ -286,7 +286,9 @@ struct WalkShade {
     uint32_t _pad;
     double* path_radiance;
     uint32_t* hist;             // may be null
-    uint32_t* stack_ovf;        // OVF kernels: stack rows beyond OVF_LDS_ROWS, [row][launched lane]
+    uint32_t* stack_ovf;        // OVF kernels: stack rows beyond the LDS ones, [row][launched lane]
+    uint32_t ovf_lds_rows;      // OVF kernels: rows kept in LDS (OVF_LDS_ROWS; RT_HIP_OVF_LDS_ROWS lowers it for tests)
+    uint32_t _pad2;
 };
 // OVF: the LDS stack holds OVF_LDS_ROWS entries per lane whatever the tree's worst case is, and deeper entries go to a
 // per-lane column in device memory.  A wave's LDS decides how many waves a CU holds: 48 or 64 rows (trees of 5 M+
@@ -294,11 +296,22 @@ struct WalkShade {
 // the number of waves in flight.  Real traversals stay far below the worst case the builder computes, so the overflow
 // rows are touched by few lanes.
 constexpr uint32_t OVF_LDS_ROWS = 32;
-template <class BoxT, int WIDTH, bool STATS, bool SHADE, bool OVF>
+static uint32_t ovf_lds_rows() {
+    const char* e = getenv("RT_HIP_OVF_LDS_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 4 && v <= (int)OVF_LDS_ROWS ? (uint32_t)v : OVF_LDS_ROWS;
+}
+// MODE of a walk kernel: plain; OVF (above); ALL = every lane fetches (below, at the loads) — for scenes that live in the
+// caches, which are not the ones with deep trees, so the two are never combined.  (A run-time switch instead of an instance
+// per mode costs two registers, and the kernel sits exactly at the count that lets a fifth wave of another kernel onto
+// the SIMD.)
+enum { WALK_PLAIN = 0, WALK_OVF = 1, WALK_ALL = 2 };
+template <class BoxT, int WIDTH, bool STATS, bool SHADE, int MODE>
 __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, const QueueGeom qg, double t_min, double t_max,
                                           const HitBuf hb, unsigned long long* counters, const WalkShade sh) {
     // (by VALUE on purpose: through references the compiler turned the base-pointer select of the fetch below into a
     // select of ADDRESSES inside the argument block plus a per-lane load — one more dependent memory round trip per step)
+    constexpr bool OVF = MODE == WALK_OVF;
     extern __shared__ uint32_t stack_mem[];
     uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
     const uint32_t tid = threadIdx.x;
@@ -307,8 +320,9 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
 #define RT_OVF_AT(row) sh.stack_ovf[((uint32_t)(row) * gridDim.x + blockIdx.x) * (uint32_t)TRACE_BLOCK + tid]      // (< 2^32: the launcher checks)
     // `deep` (wave-uniform, set once per step): some lane's stack may reach the overflow rows in this step; otherwise the
     // pushes and pops are the plain LDS ones — one compare and one scalar branch per step instead of a check per access
-#define RT_PUSH(v) { if (!OVF || !deep || (uint32_t)sp < OVF_LDS_ROWS) stack[sp][tid] = (v); else RT_OVF_AT((uint32_t)sp - OVF_LDS_ROWS) = (v); ++sp; }
-#define RT_POP() (--sp, (!OVF || !deep || (uint32_t)sp < OVF_LDS_ROWS) ? stack[sp][tid] : RT_OVF_AT((uint32_t)sp - OVF_LDS_ROWS))
+    const uint32_t lds_rows = sh.ovf_lds_rows;      // (a scalar; only the OVF instances read it)
+#define RT_PUSH(v) { if (!OVF || !deep || (uint32_t)sp < lds_rows) stack[sp][tid] = (v); else RT_OVF_AT((uint32_t)sp - lds_rows) = (v); ++sp; }
+#define RT_POP() (--sp, (!OVF || !deep || (uint32_t)sp < lds_rows) ? stack[sp][tid] : RT_OVF_AT((uint32_t)sp - lds_rows))
     // The queue's counts are read once here (size in waves, total) and looked up again per refill through the scalar
     // cache (slot_light): nothing of them stays in a VGPR across the loop — the kernel's register count decides whether
     // a camera-ray or shading wave of another pass still fits next to four of its waves on a SIMD.
@@ -413,15 +427,22 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             continue;
         }
         if (STATS) ++n_iters;
-        const bool deep = OVF && __ballot((uint32_t)sp > OVF_LDS_ROWS - 3u) != 0ull;
+        const bool deep = OVF && __ballot((uint32_t)sp + 3u > lds_rows) != 0ull;
         // One dependent memory round trip per iteration for every lane: a node lane fetches its 64-byte node,
         // a leaf lane ONE primitive of its leaf (80-byte triangle / 64-byte sphere); a leaf of n primitives
         // takes n iterations (the reference keeps count and first, so it is advanced in place).  All loads are
         // issued before anything waits, whatever mix of node and leaf lanes the wave holds.  (The BVH2 walk loads its
         // node inside the node step instead: it is the fallback, not the fast path.)
-        const uint32_t first = cur & REF_FIRST_MASK;
         const bool tri_leaf = at_leaf && !(cur & REF_SPHERE);
-        const bool node_load = W4 && at_node;
+        // BVH4 walks of scenes that live in the caches (MODE ALL; DScene::all_lanes_load, set at scene creation): EVERY lane loads — a lane
+        // without work reads node 0, one line for all of them — so the loads need no masked region and the fetch registers no
+        // zeroing: 30 instructions fewer per step (+1.2 % frame rate on the 1 M-triangle scene).  Scenes beyond the caches are
+        // bound by memory requests, not by instruction issue: there the extra requests cost 1 %, and the lanes sit out.
+        // (Every scene buffer is padded by 256 bytes: the widest record read here is 112 bytes, whatever lies at the address.)
+        constexpr bool all_load = W4 && MODE == WALK_ALL;
+        const bool idle = all_load && cur == REF_EMPTY;
+        const uint32_t first = idle ? 0u : cur & REF_FIRST_MASK;
+        const bool node_load = W4 && (at_node || idle);
         // base + index * stride with the three selected separately: one multiply-add instead of three masked address paths
         const char* base_ = node_load ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
                                       : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
@@ -429,9 +450,14 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
         const char* src = base_ + (uint64_t)first * stride_;            // (node indices are below 2^28 as well)
         const uint4* p = reinterpret_cast<const uint4*>(src);
         uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
-        if (node_load || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
-        if (tri_leaf || (F32_NODES && at_node)) e = p[4];
-        if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
+        if (all_load) {
+            a = p[0]; b = p[1]; c = p[2]; r = p[3]; e = p[4];
+            if (F32_NODES) { f = p[5]; g = p[6]; }
+        } else {
+            if (node_load || at_leaf) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; }      // idle lanes hold REF_EMPTY: no address
+            if (tri_leaf || (F32_NODES && at_node)) e = p[4];
+            if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
+        }
 #ifdef RT_TIMING
         RT_STAMP(tm_issue)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -562,20 +588,20 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
 // k_walk_shade is the persistent trace-and-shade kernel.  Separate __global__ functions so that each has its own
 // register budget: RT_TAIL_WAVES caps k_walk_shade's (its shading code wants ~200 VGPRs; held by long-lived waves they
 // would keep the other passes' kernels out of the SIMDs).
-template <class BoxT, int WIDTH, bool STATS, bool OVF>
+template <class BoxT, int WIDTH, bool STATS, int MODE>
 __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
                                                                        HitBuf hb, unsigned long long* counters, WalkShade sh) {
-    walk_body<BoxT, WIDTH, STATS, false, OVF>(S, q, qg, t_min, t_max, hb, counters, sh);
+    walk_body<BoxT, WIDTH, STATS, false, MODE>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
 #ifdef RT_TAIL_WAVES
 #define RT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(RT_TAIL_WAVES, RT_TAIL_WAVES)))
 #else
 #define RT_TAIL_ATTR
 #endif
-template <class BoxT, int WIDTH, bool STATS, bool OVF>
+template <class BoxT, int WIDTH, bool STATS, int MODE>
 __global__ RT_TAIL_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk_shade(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
                                                                            HitBuf hb, unsigned long long* counters, WalkShade sh) {
-    walk_body<BoxT, WIDTH, STATS, true, OVF>(S, q, qg, t_min, t_max, hb, counters, sh);
+    walk_body<BoxT, WIDTH, STATS, true, MODE>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1108,7 +1134,7 @@ static bool refill_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); retur
 static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
 
 // n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
-template <class BoxT, int WIDTH, bool STATS, bool SHADE, bool OVF>
+template <class BoxT, int WIDTH, bool STATS, bool SHADE, int MODE>
 static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
                           HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, uint32_t ovf_waves,
                           hipStream_t s) {
@@ -1116,7 +1142,8 @@ static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint
     // the occupancy query is per (kernel instance, stack size); a handful of values occur
     static unsigned cached_slots[5] = {0, 0, 0, 0, 0};
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
-    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, OVF>; else return k_walk<BoxT, WIDTH, STATS, OVF>; }();
+    constexpr bool OVF = MODE == WALK_OVF;
+    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
     if (!cached_slots[ci]) cached_slots[ci] = resident_waves(kernel, lds);
     const unsigned chunks = (n_upper + 63u) / 64u;
     // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks.
@@ -1147,27 +1174,31 @@ static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint
     WalkShade w;
     if (sh) w = *sh; else memset(&w, 0, sizeof(w));
     w.stack_ovf = nullptr;
+    auto go = [&](auto mode, uint32_t rows, uint32_t ovf_waves) {
+        constexpr int M = decltype(mode)::value;
+        if (sh) {
+            if (stats) launch_walk_k<BoxT, WIDTH, true, true, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            else launch_walk_k<BoxT, WIDTH, false, true, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+        } else {
+            if (stats) launch_walk_k<BoxT, WIDTH, true, false, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            else launch_walk_k<BoxT, WIDTH, false, false, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+        }
+    };
     if constexpr (WIDTH == 4) {
         // deep trees: 32 rows in LDS, the rest in the caller's overflow buffer (persistent launches only: a column per launched lane)
-        if (need > OVF_LDS_ROWS && ovf.rows && need <= OVF_LDS_ROWS + ovf.rows_cap && ovf.waves && refill_enabled()) {
+        const uint32_t lds_rows = ovf_lds_rows();
+        if (need > lds_rows && ovf.rows && need <= lds_rows + ovf.rows_cap && ovf.waves && refill_enabled()) {
             w.stack_ovf = ovf.rows;
-            if (sh) {
-                if (stats) launch_walk_k<BoxT, 4, true, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
-                else launch_walk_k<BoxT, 4, false, true, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
-            } else {
-                if (stats) launch_walk_k<BoxT, 4, true, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
-                else launch_walk_k<BoxT, 4, false, false, true>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, OVF_LDS_ROWS, ovf.waves, s);
-            }
+            w.ovf_lds_rows = lds_rows;
+            go(std::integral_constant<int, WALK_OVF>(), lds_rows, ovf.waves);
+            return;
+        }
+        if (S.all_lanes_load) {
+            go(std::integral_constant<int, WALK_ALL>(), entries, 0u);
             return;
         }
     }
-    if (sh) {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
-        else launch_walk_k<BoxT, WIDTH, false, true, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
-    } else {
-        if (stats) launch_walk_k<BoxT, WIDTH, true, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
-        else launch_walk_k<BoxT, WIDTH, false, false, false>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, entries, 0, s);
-    }
+    go(std::integral_constant<int, WALK_PLAIN>(), entries, 0u);
 }
 static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
                             HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
@@ -1185,9 +1216,10 @@ static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, ui
         launch_walk_b<Box64, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
 }
 uint32_t stack_overflow_rows(const DScene& S) {
-    static const bool off = getenv("RT_HIP_NO_STACK_OVF") && atoi(getenv("RT_HIP_NO_STACK_OVF")) == 1;
+    const bool off = getenv("RT_HIP_NO_STACK_OVF") && atoi(getenv("RT_HIP_NO_STACK_OVF")) == 1;
     const bool w4 = S.stack4 <= (uint32_t)BVH4_MAX_STACK && (S.nodes4 || S.nodes4f);
-    return (!off && w4 && S.stack4 > OVF_LDS_ROWS) ? S.stack4 - OVF_LDS_ROWS : 0u;
+    const uint32_t lds_rows = ovf_lds_rows();
+    return (!off && w4 && S.stack4 > lds_rows) ? S.stack4 - lds_rows : 0u;
 }
 void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb, bool stats,
                  unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {

@@ -139,7 +139,7 @@ struct DScene {
     uint32_t bvh_depth;          // deepest child reference = traversal stack entries needed
     QuantGrid grid;              // of nodes16 and nodes4
     uint32_t stack4;             // traversal stack entries nodes4 / nodes4f need in the worst case
-    uint32_t _pad2[1];
+    uint32_t all_lanes_load;     // BVH4 walks: lanes without work fetch node 0 instead of sitting out the loads (see walk_body)
     double grid_inv_cell[3];     // 1 / grid.cell (f64): a ray is moved into cell units with a multiplication
     rt_sky sky;
 };

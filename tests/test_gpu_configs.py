@@ -190,6 +190,29 @@ def test_kernel_variants_render_the_same_image(monkeypatch, textured):
         monkeypatch.delenv(var)
 
 
+def test_walk_kernel_modes_give_the_same_hits_and_image(monkeypatch, textured, oracle):
+    """The three instances of the BVH4 walk — plain, every-lane-fetches (scenes that live in the caches:
+    RT_HIP_ALL_LANES_LOAD, read when the scene is created) and overflow stack (deep trees; RT_HIP_OVF_LDS_ROWS=4 keeps
+    only four stack rows in LDS, so nearly every push and pop of this small scene goes through the device-memory rows)
+    — find the same (prim, t) as the oracle and render the same image bit for bit."""
+    desc, world, orc = textured
+    rays = random_rays(40_000, 29)
+    want = orc.hit(rays, mode=oracle.BRUTE)
+    cam = textured_camera(160, 90, 6, 50)
+    kw = dict(spp=6, seed=3, max_paths_in_flight=160 * 90 * 2, with_stats=True)
+    base, st0 = cam.render_image(world, **kw)
+    assert_hits_equal(world.hit(rays), want)
+    for var, val in (("RT_HIP_ALL_LANES_LOAD", "0"), ("RT_HIP_ALL_LANES_LOAD", "1"), ("RT_HIP_OVF_LDS_ROWS", "4"),
+                     ("RT_HIP_OVF_LDS_ROWS", "12")):
+        monkeypatch.setenv(var, val)
+        w2 = World.build(desc)
+        assert_hits_equal(w2.hit(rays), want)
+        img, st = cam.render_image(w2, **kw)
+        monkeypatch.delenv(var)
+        assert np.array_equal(img, base), (var, val)
+        assert int(st["ray_segments"]) == int(st0["ray_segments"]), (var, val)
+
+
 def test_coherent_wave_kernel_hits_equal_per_lane_kernel(monkeypatch, textured, oracle):
     """k_trace_packet (what rt_render uses for camera rays) against k_trace4 (what rt_trace_primary uses) and the
     oracle, on the same camera rays: (prim, t) identical.  RT_HIP_PRIMARY_PACKET routes rt_trace_primary through it."""
