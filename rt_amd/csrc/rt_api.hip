@@ -446,10 +446,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     // Depth from which the persistent trace-and-shade kernel takes over.  Stand-alone k_walk + k_shade launches are the
     // efficient way through a queue of any size (full occupancy, half the registers), the persistent kernel is the way
     // through the few thousand paths that are left after some bounces (one launch, no matter how deep they go): the
-    // switch follows the sizes the passes report — one depth later while the persistent kernel still receives more than
-    // TAIL_MAX_PATHS paths, one earlier when the last stand-alone pair saw fewer than a quarter of that.
-    // RT_HIP_TAIL_DEPTH=<d> fixes it (tests, A/B).  The image does not depend on it.
-    constexpr uint32_t TAIL_MAX_PATHS = 1u << 15;
+    // switch follows the sizes the passes report: it goes to the first depth whose queue has at most TAIL_MAX_PATHS paths —
+    // read from the reported sizes where a stand-alone pair ran, extrapolated with the last decay ratio beyond them (the
+    // persistent kernel reports only the size it starts with) — and comes back one depth when the last stand-alone pair
+    // saw fewer than a quarter of that.  RT_HIP_TAIL_DEPTH=<d> fixes it (tests, A/B).  The image does not depend on it.
+    const uint32_t TAIL_MAX_PATHS = (uint32_t)std::max(1, env_int("RT_HIP_TAIL_MAX_PATHS", 1 << 15));
     const int td_env = env_int("RT_HIP_TAIL_DEPTH", 0);
     auto tail_depth_now = [&]() -> uint32_t { return td_env > 0 ? (uint32_t)td_env : sc->tail_depth; };
     const int stagger_mode = env_int("RT_HIP_STAGGER", 1);
@@ -496,8 +497,21 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             if (w.h_hist[d] && P.n) sc->alive_ratio[d] = (double)w.h_hist[d] / (double)P.n;
         const uint32_t td = P.tail_depth;
         if (td_env <= 0 && td == sc->tail_depth && td < (uint32_t)HIST_DEPTHS) {
-            if (w.h_hist[td] > TAIL_MAX_PATHS && td + 1 < (uint32_t)HIST_DEPTHS) sc->tail_depth = td + 1;
-            else if (td > 2 && w.h_hist[td - 1] < TAIL_MAX_PATHS / 4) sc->tail_depth = td - 1;
+            const uint32_t cap = std::min<uint32_t>((uint32_t)HIST_DEPTHS - 1u, std::max(2u, cam->max_depth));
+            if (w.h_hist[td] > TAIL_MAX_PATHS && td < cap) {
+                uint32_t more = 1;
+                double r = 0.5;                                                            // paths that survive a bounce
+                if (td >= 2 && w.h_hist[td - 1] > w.h_hist[td]) {
+                    r = (double)w.h_hist[td] / (double)w.h_hist[td - 1];
+                    more = (uint32_t)std::ceil(std::log((double)TAIL_MAX_PATHS / (double)w.h_hist[td]) / std::log(r));
+                }
+                sc->tail_depth = std::min(cap, td + std::max(1u, more));
+                // the stand-alone launches of the depths in between are sized by the same extrapolation until they report
+                for (uint32_t d = td + 1; d <= sc->tail_depth && d < (uint32_t)HIST_DEPTHS; ++d)
+                    if (!(sc->alive_ratio[d] > 0.0)) sc->alive_ratio[d] = sc->alive_ratio[d - 1] * r;
+            } else if (td > 2 && w.h_hist[td - 1] < TAIL_MAX_PATHS / 4) {
+                sc->tail_depth = td - 1;
+            }
         }
         P.in_flight = false;
         return RT_OK;
@@ -629,6 +643,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         if ((rc = collect(pipes[k]))) return rc;
     HIPCHK(hipGetLastError());
     st.seconds_total = now_s() - t0;
+    if (getenv("RT_HIP_DEBUG_UTIL")) {
+        fprintf(stderr, "[rt_hip] tail depth %u; queue sizes by depth (last pass of pipe 0):", sc->tail_depth);
+        for (int d = 1; d < HIST_DEPTHS && pipes[0].w->h_hist[d]; ++d) fprintf(stderr, " %u", pipes[0].w->h_hist[d]);
+        fprintf(stderr, "\n");
+    }
     st.ray_segments = st.primary_segments;
     for (int k = 0; k < n_pipes; ++k) {
         const unsigned long long* h = pipes[k].w->h_stat;
