@@ -350,9 +350,13 @@ def main():
                          "rays_per_s": bounce_seg / bounce_s if bounce_s > 0 else 0.0,
                          # the same kernel with one pass in flight (one extra untimed frame after the timed region)
                          "alone": roof_alone,
-                         "note": "BVH+triangles (%.0f MB) are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak; "
-                                 "several passes run on their own streams in the timed region, so its event-timed kernel durations include "
-                                 "time shared with the other passes; 'alone' is the same kernel with one pass in flight" % (info["device_bytes"] / 2 ** 20)},
+                         "note": ("BVH+triangles (%.0f MB) %s; several passes run on their own streams in the timed region, so its "
+                                  "event-timed kernel durations include time shared with the other passes; 'alone' is the same kernel "
+                                  "with one pass in flight") % (info["device_bytes"] / 2 ** 20,
+                                  "are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak"
+                                  if info["device_bytes"] <= 256 << 20 else
+                                  "exceed the 256 MB Infinity Cache: the top of the tree is served by the caches, the rest by HBM "
+                                  "(compare 'traffic', the measured HBM bytes per launch, with achieved x avg_launch_ms)")},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic,
                                 "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading); bytes counted per WAVE "
