@@ -239,7 +239,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from rt_amd.distributed import hip_render_sum, render_distributed
+    from rt_amd.distributed import hip_render_sum, hip_resolve, render_distributed
 
     def step(collect=False, spp_override=None):
         """One pass of the hot path: render this rank's sample indices, RCCL sum-reduce, resolve."""
@@ -249,7 +249,8 @@ def main():
             box["st"] = hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect)
             return box["st"]
 
-        mean, st = render_distributed(render_sum, rgb_sum, spp_override or spp, seed=2024)
+        mean, st = render_distributed(render_sum, rgb_sum, spp_override or spp, seed=2024,
+                                      resolve=lambda s, total: hip_resolve(s, total, local_rank))
         if mean is not None:
             rgb_mean.copy_(mean)
         return st

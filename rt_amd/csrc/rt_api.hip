@@ -81,27 +81,6 @@ int select_device(int device) {
     return RT_OK;
 }
 
-// frees a list of device allocations unless released
-struct DevAllocs {
-    std::vector<void*> ptrs;
-    ~DevAllocs() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-    template <class T>
-    int alloc(T** out, size_t count) {
-        void* p = nullptr;
-        size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorName(e));
-        }
-        ptrs.push_back(p);
-        *out = (T*)p;
-        return RT_OK;
-    }
-};
-
 constexpr int MAX_PIPES = 8;
 
 // ---- scratch of rt_trace_closest_noalloc (include/rt_hip.h) -------------------------------------
@@ -160,6 +139,10 @@ struct rt_scene {
     hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
     hipStream_t hi_stream[MAX_PIPES] = {};       // high-priority side stream of each pipe (the short phases of a pass)
     hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {}, ev_bulk[MAX_PIPES] = {};
+    // grow-only device buffers for the host-facing entry points (the frame of rt_render, the ray / hit staging of
+    // rt_trace_closest and rt_trace_primary): no hipMalloc / hipFree per call once they have their size
+    void* io[2] = {nullptr, nullptr};
+    size_t io_cap[2] = {0, 0};
     // progressive preview state (rt_render_pass): per-pass sums, the running float frame and the 8-bit linear frame
     double* pv_sum = nullptr;
     double* pv_mean = nullptr;
@@ -290,6 +273,26 @@ int upload(rt_scene* sc, const std::vector<T>& v, const T** out) {
     sc->info.device_bytes += bytes;
     if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)p;
+    return RT_OK;
+}
+
+// sc->io[which] with at least `bytes` bytes (called with the scene's mutex held and its device current)
+template <class T>
+int scene_io(rt_scene* sc, int which, size_t count, T** out) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    if (sc->io_cap[which] < bytes) {
+        if (sc->io[which]) (void)hipFree(sc->io[which]);
+        sc->io[which] = nullptr;
+        sc->io_cap[which] = 0;
+        hipError_t e = hipMalloc(&sc->io[which], bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            sc->io[which] = nullptr;
+            return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorName(e));
+        }
+        sc->io_cap[which] = bytes;
+    }
+    *out = (T*)sc->io[which];
     return RT_OK;
 }
 
@@ -668,6 +671,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.wave_node_fetches_primary += hp[STAT_WAVE_NODES];
             st.wave_prim_fetches_primary += hp[STAT_WAVE_PRIMS];
             if (getenv("RT_HIP_DEBUG_UTIL")) {      // bounce launches: lane steps / (64 x wave loop iterations)
+                fprintf(stderr, "[rt_hip] pipe %d camera rays: %llu node records fetched per wave-launch, %llu of them dead ends "
+                        "(no ray entered a child), %llu primitive records\n", k, hp[STAT_WAVE_NODES], hp[STAT_LEAVES], hp[STAT_WAVE_PRIMS]);
                 fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
                         k, hb_[STAT_NODES], hb_[STAT_LEAVES], hb_[STAT_ITERS],
                         hb_[STAT_ITERS] ? (double)(hb_[STAT_NODES] + hb_[STAT_LEAVES]) / (64.0 * (double)hb_[STAT_ITERS]) : 0.0);
@@ -1149,6 +1154,8 @@ void rt_scene_destroy(rt_scene* sc) {
         if (sc->pv_sum) (void)hipFree(sc->pv_sum);
         if (sc->pv_mean) (void)hipFree(sc->pv_mean);
         if (sc->pv_rgba8) (void)hipFree(sc->pv_rgba8);
+        for (void* p : sc->io)
+            if (p) (void)hipFree(p);
         for (void* p : sc->allocs) (void)hipFree(p);
     }
     (void)hipGetLastError();
@@ -1176,11 +1183,10 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     if ((rc = ensure_workspace(sc, chunk))) return rc;
     Workspace& w = sc->ws[0];
-    DevAllocs tmp;
     rt_ray* d_rays = nullptr;
     rt_hit* d_hits = nullptr;
-    if ((rc = tmp.alloc(&d_rays, chunk))) return rc;
-    if ((rc = tmp.alloc(&d_hits, chunk))) return rc;
+    if ((rc = scene_io(sc, 0, chunk, &d_rays))) return rc;
+    if ((rc = scene_io(sc, 1, chunk, &d_hits))) return rc;
     hipStream_t stream = nullptr;
     const bool want_stats = stats != nullptr;
     unsigned long long* sg = w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE;
@@ -1274,11 +1280,10 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     if ((rc = select_device(sc->device))) return rc;
     if ((rc = ensure_workspace(sc, npix))) return rc;
     Workspace& w = sc->ws[0];
-    DevAllocs tmp;
     rt_hit* d_hits = nullptr;
     rt_ray* d_rays = nullptr;
-    if ((rc = tmp.alloc(&d_hits, npix))) return rc;
-    if (rays_out && (rc = tmp.alloc(&d_rays, npix))) return rc;
+    if ((rc = scene_io(sc, 1, npix, &d_hits))) return rc;
+    if (rays_out && (rc = scene_io(sc, 0, npix, &d_rays))) return rc;
     PassParams pp;
     pp.cam = *cam;
     pp.seed = seed;
@@ -1349,9 +1354,8 @@ int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, do
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
     const size_t nval = (size_t)cam->width * cam->height * 3;
-    DevAllocs tmp;
     double* d_sum = nullptr;
-    if ((rc = tmp.alloc(&d_sum, nval))) return rc;
+    if ((rc = scene_io(sc, 0, nval, &d_sum))) return rc;
     hipStream_t stream = nullptr;
     HIPCHK(hipMemsetAsync(d_sum, 0, nval * sizeof(double), stream));
     if ((rc = render_into(sc, cam, opts, d_sum, stream, stats))) return rc;

@@ -665,6 +665,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
     double best = t_max, bu = 0.0, bv = 0.0;
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0, w_nodes = 0, w_prims = 0;      // per lane / per wave (records the wave fetched)
+    uint32_t w_dead = 0;                                              // node records no lane's ray entered a child of
     unsigned long long mask = __ballot(active);
     // Camera rays of a few neighbouring pixels nearly always agree on the sign of each direction component; then the
     // near and far plane of every box are the same for the whole wave and are picked with scalar selects.
@@ -735,6 +736,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                 cur = cr; mask = mr;
                 continue;
             }
+            if (STATS) ++w_dead;
         } else {
             const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
             if (STATS && mine) n_prims += count;
@@ -793,6 +795,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             atomicAdd(&counters[STAT_PRIMS], b);
             atomicAdd(&counters[STAT_WAVE_NODES], (unsigned long long)w_nodes);
             atomicAdd(&counters[STAT_WAVE_PRIMS], (unsigned long long)w_prims);
+            atomicAdd(&counters[STAT_LEAVES], (unsigned long long)w_dead);      // (this group's leaf-step slot is otherwise unused)
         }
     }
 }

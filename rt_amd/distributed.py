@@ -33,10 +33,21 @@ def hip_render_sum(world_handle, cam, spp, sample_offset, sample_stride, seed, o
     return st[0]
 
 
-def render_distributed(render_sum, out_sum, spp_per_rank, seed=0):
+def hip_resolve(out_sum, total_spp, device):
+    """sum / total_spp on the device through the C ABI (rt_resolve_device, src/camera.rs:324); returns a new tensor."""
+    from ._lib import check, lib
+    mean = torch.empty_like(out_sum)
+    stream = torch.cuda.current_stream().cuda_stream
+    check(lib().rt_resolve_device(C.c_void_p(out_sum.data_ptr()), C.c_void_p(mean.data_ptr()), out_sum.numel(), int(total_spp),
+                                  int(device), C.c_void_p(stream)))
+    return mean
+
+
+def render_distributed(render_sum, out_sum, spp_per_rank, seed=0, resolve=None):
     """Every rank calls this.  render_sum(spp, offset, stride, seed, out_sum) must ADD the rank's
     per-pixel sums into out_sum (a float64 tensor, zeroed here).  Returns (mean or None, stats):
-    the mean image only on rank 0."""
+    the mean image only on rank 0.  resolve(out_sum, total_spp) -> mean: the division on rank 0 (default: a torch
+    division; GPU hosts pass hip_resolve so that the library's own resolve kernel runs)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     out_sum.zero_()
@@ -44,5 +55,7 @@ def render_distributed(render_sum, out_sum, spp_per_rank, seed=0):
     stats = render_sum(spp, off, stride, seed, out_sum)
     if dist.is_initialized():
         dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
-    mean = out_sum / float(spp_per_rank * world) if rank == 0 else None
+    mean = None
+    if rank == 0:
+        mean = resolve(out_sum, spp_per_rank * world) if resolve else out_sum / float(spp_per_rank * world)
     return mean, stats
