@@ -1049,6 +1049,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->d.stack4 = 0;
         bool use16 = false, use4 = false, use4f = false;
         size_t n_nodes4 = 0;
+        std::vector<Node4> n4;          // uploaded below, as the head of the BVH4 walk's record pool
+        std::vector<Node4f> n4f;
         if (use32) {
             std::vector<Node32> n32;
             narrow_nodes(bvh.nodes, n32);
@@ -1063,10 +1065,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                 for (int k = 0; k < 3; ++k) sc->d.grid_inv_cell[k] = 1.0 / (double)sc->d.grid.cell[k];
                 if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
                 use16 = true;
-                std::vector<Node4> n4;
                 uint32_t need = 0;
                 if ((!force16 || force4) && widen_nodes(bvh.nodes, sc->d.grid, n4, need) && need <= (uint32_t)BVH4_MAX_STACK) {
-                    if ((rc = upload(sc, n4, &sc->d.nodes4))) return rc;
                     sc->d.stack4 = need;
                     n_nodes4 = n4.size();
                     use4 = true;
@@ -1079,11 +1079,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             // no usable grid: the BVH4 with f32 boxes (RT_HIP_NODE_BOXES=f32 keeps the BVH2 for A/B, =w4f forces this one)
             const bool force4f = nb && strcmp(nb, "w4f") == 0;
             if ((!use16 && !no16) || force4f) {
-                std::vector<Node4f> n4f;
                 uint32_t need = 0;
                 if (widen_nodes_f32(bvh.nodes, n4f, need) && need <= (uint32_t)BVH4_MAX_STACK) {
-                    if ((rc = upload(sc, n4f, &sc->d.nodes4f))) return rc;
-                    sc->d.nodes4 = nullptr;
                     sc->d.stack4 = need;
                     n_nodes4 = n4f.size();
                     use4 = true;
@@ -1093,8 +1090,62 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         } else {
             if ((rc = upload(sc, bvh.nodes, &sc->d.nodes64))) return rc;
         }
-        if ((rc = upload(sc, tg, &sc->d.tris))) return rc;
-        if ((rc = upload(sc, sg, &sc->d.sphs))) return rc;
+        // ---- the BVH4 walk's record pool: [nodes4 or nodes4f | tris | sphs] in one allocation, child references of the
+        // BVH4 nodes re-expressed as pool offsets in 16-byte units (DScene::pool4).  A pool beyond 4 GB (some 40 M
+        // triangles) cannot be addressed with 28 bits: such a scene is walked through its BVH2.
+        sc->d.pool4 = nullptr;
+        if (use4) {
+            const size_t node_bytes = use4f ? n4f.size() * sizeof(Node4f) : n4.size() * sizeof(Node4);
+            const size_t tri_off = (node_bytes + 127) & ~size_t(127), sph_off = tri_off + tg.size() * sizeof(TriGeom);
+            const size_t total = sph_off + sg.size() * sizeof(SphGeom);
+            if (total + 4096 >= (size_t(1) << 32)) {
+                use4 = use4f = false;
+                sc->d.stack4 = 0;
+                n_nodes4 = 0;
+            } else {
+                const uint32_t node_units = (uint32_t)((use4f ? sizeof(Node4f) : sizeof(Node4)) / 16);
+                const uint32_t tri_units = (uint32_t)(sizeof(TriGeom) / 16), sph_units = (uint32_t)(sizeof(SphGeom) / 16);
+                const uint32_t tri_base = (uint32_t)(tri_off / 16), sph_base = (uint32_t)(sph_off / 16);
+                const size_t n_nodes = use4f ? n4f.size() : n4.size();
+                bool ok = true;
+                auto recode = [&](uint32_t ref) -> uint32_t {
+                    if (ref == REF_EMPTY) return ref;
+                    const uint64_t first = ref & REF_FIRST_MASK;
+                    uint64_t unit;
+                    if (!(ref & REF_LEAF)) { ok = ok && first < n_nodes; unit = first * node_units; }
+                    else if (ref & REF_SPHERE) { ok = ok && first + ((ref >> 28) & 3u) < sg.size(); unit = sph_base + first * sph_units; }
+                    else { ok = ok && first + ((ref >> 28) & 3u) < tg.size(); unit = tri_base + first * tri_units; }
+                    ok = ok && unit <= REF_FIRST_MASK - 8u;
+                    return (ref & ~REF_FIRST_MASK) | (uint32_t)(unit & REF_FIRST_MASK);
+                };
+                if (use4f) { for (auto& nd : n4f) for (auto& c : nd.child) c = recode(c); }
+                else { for (auto& nd : n4) for (auto& c : nd.child) c = recode(c); }
+                if (!ok) return fail(RT_ERR_INVALID, "internal: a BVH4 child reference points outside its arrays");
+                char* pool_d = nullptr;
+                hipError_t e = hipMalloc((void**)&pool_d, total + 256);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(RT_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", total + 256, hipGetErrorName(e));
+                }
+                sc->allocs.push_back(pool_d);
+                sc->info.device_bytes += total + 256;
+                if (tri_off > node_bytes) HIPCHK(hipMemset(pool_d + node_bytes, 0, tri_off - node_bytes));
+                HIPCHK(hipMemset(pool_d + total, 0, 256));
+                if (use4f) HIPCHK(hipMemcpy(pool_d, n4f.data(), node_bytes, hipMemcpyHostToDevice));
+                else HIPCHK(hipMemcpy(pool_d, n4.data(), node_bytes, hipMemcpyHostToDevice));
+                if (!tg.empty()) HIPCHK(hipMemcpy(pool_d + tri_off, tg.data(), tg.size() * sizeof(TriGeom), hipMemcpyHostToDevice));
+                if (!sg.empty()) HIPCHK(hipMemcpy(pool_d + sph_off, sg.data(), sg.size() * sizeof(SphGeom), hipMemcpyHostToDevice));
+                sc->d.pool4 = pool_d;
+                if (use4f) sc->d.nodes4f = reinterpret_cast<const Node4f*>(pool_d);
+                else sc->d.nodes4 = reinterpret_cast<const Node4*>(pool_d);
+                sc->d.tris = reinterpret_cast<const TriGeom*>(pool_d + tri_off);
+                sc->d.sphs = reinterpret_cast<const SphGeom*>(pool_d + sph_off);
+            }
+        }
+        if (!sc->d.pool4) {
+            if ((rc = upload(sc, tg, &sc->d.tris))) return rc;
+            if ((rc = upload(sc, sg, &sc->d.sphs))) return rc;
+        }
         if ((rc = upload(sc, tsh, &sc->d.tri_shade))) return rc;
         if ((rc = upload(sc, ssh, &sc->d.sph_shade))) return rc;
         if ((rc = upload(sc, mats, &sc->d.mats))) return rc;

@@ -443,11 +443,17 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
         const bool idle = all_load && cur == REF_EMPTY;
         const uint32_t first = idle ? 0u : cur & REF_FIRST_MASK;
         const bool node_load = W4 && (at_node || idle);
-        // base + index * stride with the three selected separately: one multiply-add instead of three masked address paths
-        const char* base_ = node_load ? (F32_NODES ? reinterpret_cast<const char*>(S.nodes4f) : reinterpret_cast<const char*>(S.nodes4))
-                                      : tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
-        const uint32_t stride_ = node_load ? (uint32_t)(F32_NODES ? sizeof(Node4f) : sizeof(Node4)) : tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
-        const char* src = base_ + (uint64_t)first * stride_;            // (node indices are below 2^28 as well)
+        const char* src;
+        if constexpr (W4) {
+            // BVH4 references carry the record's offset in the pool in 16-byte units (DScene::pool4): one shift, and the
+            // 32-bit byte offset rides on the scalar base — no select between three arrays and strides
+            // (the four flag bits of a reference fall off the top of the shift; a lane without work fetches record 0)
+            src = S.pool4 + (uint64_t)(idle ? 0u : cur << 4);
+        } else {
+            const char* base_ = tri_leaf ? reinterpret_cast<const char*>(S.tris) : reinterpret_cast<const char*>(S.sphs);
+            const uint32_t stride_ = tri_leaf ? (uint32_t)sizeof(TriGeom) : (uint32_t)sizeof(SphGeom);
+            src = base_ + (uint64_t)first * stride_;
+        }
         const uint4* p = reinterpret_cast<const uint4*>(src);
         uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a, f = a, g = a;
         if (all_load) {
@@ -548,7 +554,9 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
             }
             // next primitive of the same leaf, or pop
-            cur = (cur & 0x30000000u) ? cur - 0x10000000u + 1u : (sp ? RT_POP() : REF_EMPTY);
+            // (BVH4: references count 16-byte units — a triangle is 5 of them, a sphere 4)
+            const uint32_t next_ = W4 ? ((cur & REF_SPHERE) ? (uint32_t)(sizeof(SphGeom) / 16) : (uint32_t)(sizeof(TriGeom) / 16)) : 1u;
+            cur = (cur & 0x30000000u) ? cur - 0x10000000u + next_ : (sp ? RT_POP() : REF_EMPTY);
         }
 #ifdef RT_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -140,6 +140,11 @@ struct DScene {
     QuantGrid grid;              // of nodes16 and nodes4
     uint32_t stack4;             // traversal stack entries nodes4 / nodes4f need in the worst case
     uint32_t all_lanes_load;     // BVH4 walks: lanes without work fetch node 0 instead of sitting out the loads (see walk_body)
+    // BVH4 walks address ONE pool [nodes4 or nodes4f | tris | sphs]: the low 28 bits of a child reference inside nodes4 /
+    // nodes4f are the record's offset in the pool in 16-byte units (node, triangle or sphere alike), so a step's fetch
+    // address is base + (ref & mask) * 16 whatever the lane is at.  nodes4 / nodes4f, tris and sphs point into it; the
+    // references of the BVH2 node arrays keep counting records.
+    const char* pool4;
     double grid_inv_cell[3];     // 1 / grid.cell (f64): a ray is moved into cell units with a multiplication
     rt_sky sky;
 };
