@@ -137,8 +137,7 @@ struct rt_scene {
     bool device_built = false;       // BVH from bvh_gpu.hip
     Workspace ws[MAX_PIPES];         // one per in-flight pass (DEFAULT_PIPES passes are pipelined by default)
     hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
-    hipStream_t hi_stream[MAX_PIPES] = {};       // high-priority side stream of each pipe (the short phases of a pass)
-    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {}, ev_bulk[MAX_PIPES] = {};
+    hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {};
     // grow-only device buffers for the host-facing entry points (the frame of rt_render, the ray / hit staging of
     // rt_trace_closest and rt_trace_primary): no hipMalloc / hipFree per call once they have their size
     void* io[2] = {nullptr, nullptr};
@@ -402,23 +401,9 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         for (auto& e : sc->ev_acc) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : sc->ev_cam) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : sc->ev_bulk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // The short phases of a pass (shading, the tail kernel, the sums) run on a high-priority stream of their own: next to
-    // the persistent traversal waves and the camera-ray kernels of the other passes their small workgroups would otherwise
-    // wait for slots for ten times their own duration, and the pass with them.  RT_HIP_PRIO=0: everything on one stream.
-    // (More than four hardware queues per process stall for SECONDS on this platform — queues are time-sliced then —, so
-    // the side streams count against the passes in flight: mode 1 = one per pipe, at most two pipes; mode 2 = one side
-    // stream shared by all pipes, at most three pipes.)
-    const int prio_mode = env_int("RT_HIP_PRIO", 0);
-    const bool use_prio = prio_mode != 0;
-    if (use_prio) {
-        n_pipes = std::min(n_pipes, prio_mode == 1 ? 2 : 3);
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < (prio_mode == 1 ? n_pipes : 1); ++k)
-            if (!sc->hi_stream[k]) HIPCHK(hipStreamCreateWithPriority(&sc->hi_stream[k], hipStreamNonBlocking, greatest));
-    }
+    // (One stream per pass in flight and no more: beyond four hardware queues per process the queues are time-sliced on
+    // this platform and a render stalls for seconds, so the short phases of a pass get no high-priority side stream.)
     for (int k = 1; k < n_pipes; ++k)
         if (!sc->aux_stream[k]) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
 
@@ -461,8 +446,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
 
     struct Pipe {
         Workspace* w = nullptr;
-        hipStream_t s = nullptr;      // bulk phases: camera rays, first-bounce traversal
-        hipStream_t h = nullptr;      // short phases (== s without priorities)
+        hipStream_t s = nullptr;      // the stream every launch of the pipe's passes goes to
         bool in_flight = false;
         uint32_t n = 0;               // paths of the pass in flight
         uint32_t tail_depth = 0;      // and the switch depth it ran with
@@ -470,7 +454,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     for (int k = 0; k < n_pipes; ++k) {
         pipes[k].w = &sc->ws[k];
         pipes[k].s = k ? sc->aux_stream[k] : stream;
-        pipes[k].h = use_prio ? sc->hi_stream[prio_mode == 1 ? k : 0] : pipes[k].s;
     }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
@@ -556,7 +539,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         // after that every pipe runs free.  RT_HIP_STAGGER=0: no ramp, =2: every pass waits (strict camera chain).
         if (stagger && prev_pipe >= 0 && prev_pipe != k && (pass < (uint32_t)n_pipes || stagger_mode == 2))
             HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
-        if (use_prio && pass >= (uint32_t)n_pipes) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[k], 0));     // the pipe's last pass has left the workspace
         HIPCHK(hipEventRecord(w.ev[0], P.s));
         // ---- depth 0: survivors -> q[1], counts cnt[0]
         if (use_packet) {
@@ -579,14 +561,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         int cur = 1, cset = 0;
         uint32_t depth = 1;
         bool ev2 = false;
-        hipStream_t ws = P.s;                 // the stream the pass is on: it moves to the side stream after the first-bounce traversal
-        auto to_side = [&]() -> int {
-            if (ws == P.h) return RT_OK;
-            HIPCHK(hipEventRecord(sc->ev_bulk[k], P.s));
-            HIPCHK(hipStreamWaitEvent(P.h, sc->ev_bulk[k], 0));
-            ws = P.h;
-            return RT_OK;
-        };
+        hipStream_t ws = P.s;
         const uint32_t tail_depth = tail_depth_now();
         for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
@@ -594,7 +569,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.trace_launches++;
             if (depth == 1) st.bounce_launches++;
             if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], ws)); ev2 = true; }
-            if ((rc = to_side())) return rc;
             if (depth >= 2) HIPCHK(hipMemsetAsync(cnt[cset ^ 1], 0, COUNTER_BYTES, ws));      // (set last read two kernels ago)
             const uint32_t est = estimate(depth, n);
             launch_shade(sc->d, pp, depth, w.q[cur], qg, n, est, w.hb, w.q[cur ^ 1], cnt[cset ^ 1], w.path_radiance,
@@ -605,7 +579,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             cset ^= 1;
         }
         if (!ev2) HIPCHK(hipEventRecord(w.ev[2], ws));
-        if ((rc = to_side())) return rc;
         if (depth == 1) HIPCHK(hipEventRecord(w.ev[3], ws));      // (no stand-alone pair ran)
         // ---- every remaining bounce inside one persistent launch
         if (depth <= cam->max_depth) {
@@ -633,8 +606,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     }
     int first_err = RT_OK;
     for (int k = 0; k < n_pipes; ++k) {      // drain every pipe, whatever happened on another one
-        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].h);
-        if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].h);
+        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s);
         if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].s);
         if (e != hipSuccess && !first_err) {
             (void)hipGetLastError();
@@ -1193,10 +1165,6 @@ void rt_scene_destroy(rt_scene* sc) {
         for (auto& w : sc->ws) free_workspace(w);
         for (auto& a : sc->aux_stream)
             if (a) (void)hipStreamDestroy(a);
-        for (auto& a : sc->hi_stream)
-            if (a) (void)hipStreamDestroy(a);
-        for (auto& e : sc->ev_bulk)
-            if (e) (void)hipEventDestroy(e);
         if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
         for (auto& e : sc->ev_acc)
             if (e) (void)hipEventDestroy(e);
