@@ -630,6 +630,13 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
         const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
         const unsigned long long* hd = h + STAT_GROUP * STAT_GROUP_DEEP;
+#ifdef RT_TIMING
+        if (getenv("RT_HIP_DEBUG_UTIL") && hp[12])
+            fprintf(stderr, "[rt_hip] pipe %d camera-ray wave (every 64th), cycles in flight: generation %.0f, %.1f node steps %.0f (%.1f each), "
+                    "%.1f primitive steps %.0f (%.1f each), shading + append %.0f\n", k, (double)hp[8] / hp[12], (double)hp[13] / hp[12],
+                    (double)hp[9] / hp[12], (double)hp[9] / std::max(1.0, (double)hp[13]), (double)hp[14] / hp[12], (double)hp[10] / hp[12],
+                    (double)hp[10] / std::max(1.0, (double)hp[14]), (double)hp[11] / hp[12]);
+#endif
         st.bounce_segments += hb_[STAT_SEGMENTS];
         st.tail_segments += ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
         st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];

@@ -164,30 +164,47 @@ struct Box32 {
         for (int k = 0; k < 3; ++k) { lo_l[k] = nd->lo_l[k]; hi_l[k] = nd->hi_l[k]; lo_r[k] = nd->lo_r[k]; hi_r[k] = nd->hi_r[k]; }
         cl = nd->left; cr = nd->right;
     }
-    __device__ __forceinline__ bool test(const float* lo, const float* hi, float& t_near) const {
+    // the widened parametric interval [tn, tf] of the ray inside a box; accept() is the test on it
+    __device__ __forceinline__ void interval(const float* lo, const float* hi, float& tn, float& tf) const {
         const float r = 0x1.0p-22f;
         const float ax = fminf(fmaf(lo[0], ix, nx), fmaf(hi[0], ix, nx)), bx = fmaxf(fmaf(lo[0], ix, fx), fmaf(hi[0], ix, fx));
         const float ay = fminf(fmaf(lo[1], iy, ny), fmaf(hi[1], iy, ny)), by = fmaxf(fmaf(lo[1], iy, fy), fmaf(hi[1], iy, fy));
         const float az = fminf(fmaf(lo[2], iz, nz), fmaf(hi[2], iz, nz)), bz = fmaxf(fmaf(lo[2], iz, fz), fmaf(hi[2], iz, fz));
-        float tn = fmaxf(fmaxf(ax, ay), az);
-        float tf = fminf(fminf(bx, by), bz);
+        tn = fmaxf(fmaxf(ax, ay), az);
+        tf = fminf(fminf(bx, by), bz);
         tn = fmaf(-fabsf(tn), r, tn);
         tf = fmaf(fabsf(tf), r, tf);
+    }
+    __device__ __forceinline__ bool accept(float tn, float tf) const { return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t); }
+    // accept() for the whole wave as a lane mask, straight from its three compares (a NaN on either side accepts, as in
+    // accept()); written with the compare-to-mask builtin because a ballot over a computed flag goes through a 0/1
+    // register and a second compare
+    __device__ __forceinline__ unsigned long long accept_mask(float tn, float tf) const {
+        constexpr int UGE = 11;      // LLVM FCMP_UGE: unordered or >=
+        return __builtin_amdgcn_fcmpf(tf, tn, UGE) & __builtin_amdgcn_fcmpf(tf, lo_t, UGE) & __builtin_amdgcn_fcmpf(hi_t, tn, UGE);
+    }
+    __device__ __forceinline__ bool test(const float* lo, const float* hi, float& t_near) const {
+        float tn, tf;
+        interval(lo, hi, tn, tf);
         t_near = tn;
-        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
+        return accept(tn, tf);
     }
     // The same test with the near and far plane of each axis already picked by the sign of the direction (near = lo
     // when idf >= 0, hi otherwise): one fma per plane, no min/max per axis.  For finite planes and idf it returns what
     // test() returns (rounding is monotone); a ray parallel to a slab gives NaN for both planes of that axis in either
     // form, and the NaN drops out of max3 / min3 the same way.
-    __device__ __forceinline__ bool test_picked(const float* near, const float* far, float& t_near) const {
+    __device__ __forceinline__ void interval_picked(const float* near, const float* far, float& tn, float& tf) const {
         const float r = 0x1.0p-22f;
-        float tn = fmaxf(fmaxf(fmaf(near[0], ix, nx), fmaf(near[1], iy, ny)), fmaf(near[2], iz, nz));
-        float tf = fminf(fminf(fmaf(far[0], ix, fx), fmaf(far[1], iy, fy)), fmaf(far[2], iz, fz));
+        tn = fmaxf(fmaxf(fmaf(near[0], ix, nx), fmaf(near[1], iy, ny)), fmaf(near[2], iz, nz));
+        tf = fminf(fminf(fmaf(far[0], ix, fx), fmaf(far[1], iy, fy)), fmaf(far[2], iz, fz));
         tn = fmaf(-fabsf(tn), r, tn);
         tf = fmaf(fabsf(tf), r, tf);
+    }
+    __device__ __forceinline__ bool test_picked(const float* near, const float* far, float& t_near) const {
+        float tn, tf;
+        interval_picked(near, far, tn, tf);
         t_near = tn;
-        return !(tn > tf) && !(tf < lo_t) && !(tn > hi_t);
+        return accept(tn, tf);
     }
 };
 
@@ -674,6 +691,14 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0, w_nodes = 0, w_prims = 0;      // per lane / per wave (records the wave fetched)
     uint32_t w_dead = 0;                                              // node records no lane's ray entered a child of
+#ifdef RT_TIMING
+    // (instrumented builds only: cycles of the wave per phase — generation, node steps, primitive steps, shading)
+    unsigned long long pk_t0 = clock64(), pk_gen = 0, pk_node = 0, pk_prim = 0, pk_shade = 0, pk_last = 0;
+    uint32_t w_nodes_t = 0, w_prims_t = 0;
+#define RT_PK_STAMP(acc) { const unsigned long long now_ = clock64(); acc += now_ - pk_last; pk_last = now_; }
+#else
+#define RT_PK_STAMP(acc)
+#endif
     unsigned long long mask = __ballot(active);
     // Camera rays of a few neighbouring pixels nearly always agree on the sign of each direction component; then the
     // near and far plane of every box are the same for the whole wave and are picked with scalar selects.
@@ -684,9 +709,14 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                    szn_u = __builtin_amdgcn_readfirstlane(neg_z != 0 ? 1u : 0u);
     uint32_t cur = (mask && S.root != REF_EMPTY) ? S.root : REF_EMPTY;
     int sp = 0;
+#ifdef RT_TIMING
+    pk_last = pk_t0;
+    RT_PK_STAMP(pk_gen)
+#endif
 
     while (cur != REF_EMPTY) {
-        const bool mine = (mask >> lane) & 1ull;
+        const bool was_leaf_ = (cur & REF_LEAF) != 0;
+        (void)was_leaf_;
         if (!(cur & REF_LEAF)) {
             const u32x16 nd = uload16(&S.nodes32[cur]);
             const uint32_t cl = nd[12], cr = nd[13];
@@ -694,9 +724,8 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             const float hi_l[3] = {__uint_as_float(nd[3]), __uint_as_float(nd[4]), __uint_as_float(nd[5])};
             const float lo_r[3] = {__uint_as_float(nd[6]), __uint_as_float(nd[7]), __uint_as_float(nd[8])};
             const float hi_r[3] = {__uint_as_float(nd[9]), __uint_as_float(nd[10]), __uint_as_float(nd[11])};
-            float tl = 0.f, tr = 0.f;
+            float tl = 0.f, tr = 0.f, tfl = 0.f, tfr = 0.f;      // entry and exit parameter of the two boxes
             // both boxes tested without masked regions (the node is wave-uniform, the arithmetic is per lane)
-            bool tl_ok, tr_ok;
             if (same_signs) {
                 // four scalar selects per axis behind one compare (the planes sit in SGPRs; written out because the
                 // compiler sets the condition code again before every select)
@@ -711,21 +740,26 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                 const float fl[3] = {__uint_as_float(f_l[0]), __uint_as_float(f_l[1]), __uint_as_float(f_l[2])};
                 const float nr[3] = {__uint_as_float(n_r[0]), __uint_as_float(n_r[1]), __uint_as_float(n_r[2])};
                 const float fr[3] = {__uint_as_float(f_r[0]), __uint_as_float(f_r[1]), __uint_as_float(f_r[2])};
-                tl_ok = rb.test_picked(nl, fl, tl);
-                tr_ok = rb.test_picked(nr, fr, tr);
+                rb.interval_picked(nl, fl, tl, tfl);
+                rb.interval_picked(nr, fr, tr, tfr);
             } else {
-                tl_ok = rb.test(lo_l, hi_l, tl);
-                tr_ok = rb.test(lo_r, hi_r, tr);
+                rb.interval(lo_l, hi_l, tl, tfl);
+                rb.interval(lo_r, hi_r, tr, tfr);
             }
-            const bool hl = mine & tl_ok;
-            const bool hr = mine & tr_ok & (cr != REF_EMPTY);
-            if (STATS && mine) ++n_nodes;
+            // `mask` is the wave-uniform lane mask of the rays that reached this node, so "this lane's ray hits child k" as
+            // a lane mask is one scalar AND with the compare's result: no per-lane flag, no flag-to-mask round trip
+            const unsigned long long ml = mask & rb.accept_mask(tl, tfl);
+            const unsigned long long mr = cr != REF_EMPTY ? mask & rb.accept_mask(tr, tfr) : 0ull;
+            if (STATS && ((mask >> lane) & 1ull)) ++n_nodes;
             if (STATS) ++w_nodes;
-            const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+#ifdef RT_TIMING
+            ++w_nodes_t;
+#endif
             if (ml && mr) {
-                // near child first, by majority of the lanes that care
-                const int vl = __popcll(__ballot(hl && (!hr || tl <= tr)));
-                const int vr = __popcll(__ballot(hr && (!hl || tr < tl)));
+                // near child first, by majority of the lanes that care (a ray in both children votes for the nearer one)
+                const unsigned long long both = ml & mr, le = __builtin_amdgcn_fcmpf(tl, tr, 5 /* LLVM FCMP_OLE */);
+                const int vl = __popcll(ml & ~mr) + __popcll(both & le);
+                const int vr = __popcll(mr & ~ml) + __popcll(both & ~le);
                 const bool left_first = vl >= vr;
                 const unsigned long long fm = left_first ? mr : ml;
                 if (lane == 0) {
@@ -736,19 +770,26 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                 ++sp;
                 cur = left_first ? cl : cr;
                 mask = left_first ? ml : mr;
+                RT_PK_STAMP(pk_node)
                 continue;
             } else if (ml) {
                 cur = cl; mask = ml;
+                RT_PK_STAMP(pk_node)
                 continue;
             } else if (mr) {
                 cur = cr; mask = mr;
+                RT_PK_STAMP(pk_node)
                 continue;
             }
             if (STATS) ++w_dead;
         } else {
             const uint32_t first = cur & REF_FIRST_MASK, count = ((cur >> 28) & 3u) + 1u;
+            const bool mine = (mask >> lane) & 1ull;
             if (STATS && mine) n_prims += count;
             if (STATS) w_prims += count;
+#ifdef RT_TIMING
+            w_prims_t += count;
+#endif
             if (cur & REF_SPHERE) {
                 for (uint32_t k = 0; k < count; ++k) {
                     const u32x16 g = uload16(&S.sphs[first + k]);
@@ -776,7 +817,13 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         const PacketEntry e = stack[sp];
         cur = __builtin_amdgcn_readfirstlane(e.ref);
         mask = ((unsigned long long)__builtin_amdgcn_readfirstlane(e.mask_hi) << 32) | __builtin_amdgcn_readfirstlane(e.mask_lo);
+#ifdef RT_TIMING
+        if (was_leaf_) RT_PK_STAMP(pk_prim) else RT_PK_STAMP(pk_node)
+#endif
     }
+#ifdef RT_TIMING
+    RT_PK_STAMP(pk_prim)
+#endif
     if (FUSE) {
         bool alive = false;
         D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
@@ -792,6 +839,9 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         hb.bu[i] = bu;
         hb.bv[i] = bv;
     }
+#ifdef RT_TIMING
+    RT_PK_STAMP(pk_shade)
+#endif
     if (STATS) {
         unsigned long long a = n_nodes, b = n_prims;
         for (int off = 32; off; off >>= 1) {
@@ -804,8 +854,17 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             atomicAdd(&counters[STAT_WAVE_NODES], (unsigned long long)w_nodes);
             atomicAdd(&counters[STAT_WAVE_PRIMS], (unsigned long long)w_prims);
             atomicAdd(&counters[STAT_LEAVES], (unsigned long long)w_dead);      // (this group's leaf-step slot is otherwise unused)
+
         }
     }
+#ifdef RT_TIMING
+    // one wave in 64 reports (every wave reporting would queue a million atomics on five addresses and stretch what is measured)
+    if (counters && lane == 0 && (blockIdx.x & 63u) == 0u) {
+        atomicAdd(&counters[8], pk_gen); atomicAdd(&counters[9], pk_node); atomicAdd(&counters[10], pk_prim);
+        atomicAdd(&counters[11], pk_shade); atomicAdd(&counters[12], 1ull);
+        atomicAdd(&counters[13], (unsigned long long)w_nodes_t); atomicAdd(&counters[14], (unsigned long long)w_prims_t);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
