@@ -5,7 +5,7 @@
 //      k_trace_packet  the same for coherent camera rays (+ K0 and depth-0 shading fused in)
 //   K2-4 k_shade       sky on miss, Material::scatter,     src/hittable.rs:84-93, src/material.rs:94-179,
 //                      russian_roulette, compaction        src/camera.rs:280-313
-//      k_walk<SHADE>   K1 + K2-4 in one persistent kernel: a lane traces, shades and goes on with the scattered
+//      k_walk_shade    K1 + K2-4 in one persistent kernel: a lane traces, shades and goes on with the scattered
 //                      ray until its path ends, then takes the next path from the queue (the raycast recursion of
 //                      src/camera.rs:296-313 unrolled per lane)
 //   K5 k_accumulate / k_resolve   render_pixel's mean      src/camera.rs:315-325

@@ -62,7 +62,7 @@ def test_textured_triangles_closest_hits(textured, oracle):
 @pytest.mark.parametrize("spp,seed,max_depth", [(1, 0, 50), (4, 3, 50), (3, 11, 2)])
 def test_textured_triangles_render_matches_oracle(textured, oracle, spp, seed, max_depth):
     """Image texture on triangles through every hand-off of the barycentrics: the fused camera-ray kernel (depth 0),
-    k_trace4 -> k_shade (bounces), and a low max_depth so that the depth limit is reached on textured hits."""
+    k_walk -> k_shade (bounces), and a low max_depth so that the depth limit is reached on textured hits."""
     desc, world, orc = textured
     cam = textured_camera(160, 90, spp, max_depth)
     img, st = cam.render_image(world, spp=spp, seed=seed, with_stats=True)
@@ -214,7 +214,7 @@ def test_walk_kernel_modes_give_the_same_hits_and_image(monkeypatch, textured, o
 
 
 def test_coherent_wave_kernel_hits_equal_per_lane_kernel(monkeypatch, textured, oracle):
-    """k_trace_packet (what rt_render uses for camera rays) against k_trace4 (what rt_trace_primary uses) and the
+    """k_trace_packet (what rt_render uses for camera rays) against k_walk (what rt_trace_primary uses) and the
     oracle, on the same camera rays: (prim, t) identical.  RT_HIP_PRIMARY_PACKET routes rt_trace_primary through it."""
     desc, world, orc = textured
     cover = World.build(scenes.cover_scene())
