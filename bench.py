@@ -32,10 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="heightfield_1m", choices=["heightfield_1m", "cover", "textured_5m"])
+    ap.add_argument("--workload", default="heightfield_1m", choices=["heightfield_1m", "cover", "textured_5m", "large_20m"])
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (default: the config's)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=None, help="default 1920 (3840 for large_20m)")
+    ap.add_argument("--height", type=int, default=None, help="default 1080 (2160 for large_20m)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true", help="skip the extra untimed one-pass-in-flight frame (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
@@ -44,6 +44,8 @@ def parse():
 
 def make_workload(name, width, height, spp):
     from rt_amd import scenes
+    big = name == "large_20m"
+    width, height = width or (3840 if big else 1920), height or (2160 if big else 1080)
     if name == "heightfield_1m":
         desc = scenes.heightfield_scene(quads=708)
         cam = scenes.heightfield_camera(width, height, spp or 256, 50)
@@ -52,11 +54,16 @@ def make_workload(name, width, height, spp):
         desc = scenes.cover_scene()
         cam = scenes.cover_camera(width, height, spp or 1024, 50, defocus=True)
         label = "S1 RTIOW cover scene (447 spheres + checker ground), cam2"
-    else:
+    elif name == "textured_5m":
         desc = scenes.textured_scene()
-        cam = scenes.cover_camera(width, height, spp or 1024, 50, defocus=False)
         cam = scenes.heightfield_camera(width, height, spp or 1024, 50)
         label = "S4 textured terrain + icosphere instances ~5.0M tris, widecam"
+    else:
+        # config 5's scene and frame on ONE GPU (the config itself is 8 GPUs at 4096 spp): a line for the record,
+        # run with --no-cpu-baseline (the oracle's tree over 20 M triangles takes a minute to build)
+        desc = scenes.textured_scene(terrain_quads=1414, instances=12500, tex_size=1024)
+        cam = scenes.heightfield_camera(width, height, spp or 64, 100)
+        label = "S5 textured terrain + icosphere instances ~20.0M tris, widecam, max_depth 100"
     return desc, cam, label
 
 
