@@ -4,8 +4,11 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <thread>
 
 namespace rt {
@@ -58,18 +61,106 @@ struct Task {
     BvhResult result;
 };
 
+// A few threads that stay up for the length of one build: run(n, fn) calls fn(k) once for every k in [0, n) on the
+// team and on the caller, and returns when all calls have returned.  What a run computes never depends on which thread
+// took which k (callers merge per-k results in k order, or the merge is order-free: min, max, integer sums).
+class Team {
+public:
+    explicit Team(unsigned threads) {
+        for (unsigned i = 1; i < threads; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~Team() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+            ++generation;
+        }
+        cv_job.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    unsigned size() const { return (unsigned)workers.size() + 1u; }
+    void run(size_t n, const std::function<void(size_t)>& fn) {
+        if (workers.empty() || n <= 1) {
+            for (size_t k = 0; k < n; ++k) fn(k);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = &fn;
+            total = n;
+            next.store(0);
+            busy = workers.size();
+            ++generation;
+        }
+        cv_job.notify_all();
+        drain(fn, n);
+        std::unique_lock<std::mutex> l(m);
+        cv_done.wait(l, [&] { return busy == 0; });
+        job = nullptr;
+    }
+
+private:
+    void drain(const std::function<void(size_t)>& fn, size_t n) {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= n) return;
+            fn(k);
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* fn;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv_job.wait(l, [&] { return generation != seen; });
+                seen = generation;
+                if (stop) return;
+                fn = job;
+                n = total;
+            }
+            drain(*fn, n);
+            {
+                std::lock_guard<std::mutex> l(m);
+                if (--busy == 0) cv_done.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(size_t)>* job = nullptr;
+    size_t total = 0, busy = 0;
+    std::atomic<size_t> next{0};
+    unsigned long long generation = 0;
+    bool stop = false;
+};
+
+// [0, n) in pieces of `piece` elements: piece k is [k*piece, min(n, (k+1)*piece))
+inline size_t pieces_of(size_t n, size_t piece) { return (n + piece - 1) / piece; }
+
+// Ranges of at least this many primitives are swept and partitioned in pieces (at the top of the tree by the team,
+// inside a worker's subtree one piece after the other): the partition of such a range is the STABLE one whoever runs
+// it, so the tree and the order of the primitives in its leaves do not depend on the number of threads.
+constexpr size_t PIECEWISE_MIN = 65536, PIECE = 16384;
+
 struct Shared {
     const std::vector<PrimBox>& pb;
     size_t nsph;
     std::vector<uint32_t> idx;
-    std::vector<double> cent;   // 3 per prim
-    Shared(const std::vector<PrimBox>& b, size_t ns) : pb(b), nsph(ns) {
+    std::vector<double> cent;      // 3 per prim
+    std::vector<uint32_t> spare;   // the stable partition's second buffer (a builder uses the range it owns in idx)
+    Shared(const std::vector<PrimBox>& b, size_t ns, Team& team) : pb(b), nsph(ns) {
         idx.resize(b.size());
         cent.resize(3 * b.size());
-        for (size_t i = 0; i < b.size(); ++i) {
-            idx[i] = (uint32_t)i;
-            for (int k = 0; k < 3; ++k) cent[3 * i + k] = 0.5 * (b[i].lo[k] + b[i].hi[k]);
-        }
+        if (b.size() >= PIECEWISE_MIN) spare.resize(b.size());
+        team.run(pieces_of(b.size(), PIECE), [&](size_t k) {
+            for (size_t i = k * PIECE; i < std::min(b.size(), (k + 1) * PIECE); ++i) {
+                idx[i] = (uint32_t)i;
+                for (int c = 0; c < 3; ++c) cent[3 * i + c] = 0.5 * (b[i].lo[c] + b[i].hi[c]);
+            }
+        });
     }
 };
 
@@ -81,8 +172,15 @@ struct Builder {
     BvhResult& out;
     std::vector<Task>* tasks = nullptr;
     size_t task_threshold = 0;
+    std::vector<uint32_t>& spare;   // shared like idx: the stable partition's second buffer, same ranges
+    Team* team = nullptr;           // set for the builder of the top of the tree (the only one running at that time)
 
-    Builder(Shared& sh, BvhResult& o) : pb(sh.pb), nsph(sh.nsph), idx(sh.idx), cent(sh.cent), out(o) {}
+    Builder(Shared& sh, BvhResult& o) : pb(sh.pb), nsph(sh.nsph), idx(sh.idx), cent(sh.cent), out(o), spare(sh.spare) {}
+
+    void each_piece(size_t n_pieces, const std::function<void(size_t)>& fn) const {
+        if (team) team->run(n_pieces, fn);
+        else for (size_t k = 0; k < n_pieces; ++k) fn(k);
+    }
 
     bool homogeneous(size_t first, size_t count) const {
         bool s0 = idx[first] < nsph;
@@ -117,10 +215,28 @@ struct Builder {
         }
         Box cb;
         bounds = Box();
-        for (size_t i = first; i < first + count; ++i) {
-            const PrimBox& p = pb[idx[i]];
-            bounds.grow(p.lo, p.hi);
-            cb.grow_point(&cent[3 * idx[i]]);
+        const bool piecewise = count >= PIECEWISE_MIN;
+        const size_t n_pieces = piecewise ? pieces_of(count, PIECE) : 1;
+        auto piece_end = [&](size_t k) { return first + std::min(count, (k + 1) * PIECE); };
+        if (piecewise) {
+            std::vector<Box> part(2 * n_pieces);
+            each_piece(n_pieces, [&](size_t k) {
+                Box b, c;
+                for (size_t i = first + k * PIECE; i < piece_end(k); ++i) {
+                    const PrimBox& p = pb[idx[i]];
+                    b.grow(p.lo, p.hi);
+                    c.grow_point(&cent[3 * idx[i]]);
+                }
+                part[2 * k] = b;
+                part[2 * k + 1] = c;
+            });
+            for (size_t k = 0; k < n_pieces; ++k) { bounds.grow(part[2 * k]); cb.grow(part[2 * k + 1]); }
+        } else {
+            for (size_t i = first; i < first + count; ++i) {
+                const PrimBox& p = pb[idx[i]];
+                bounds.grow(p.lo, p.hi);
+                cb.grow_point(&cent[3 * idx[i]]);
+            }
         }
         const bool can_leaf = count <= (size_t)RT_LEAF_MAX && homogeneous(first, count);
         if (count == 1) return make_leaf(first, count, depth);
@@ -128,17 +244,47 @@ struct Builder {
         // --- binned SAH over the three axes
         double best_cost = INF;
         int best_axis = -1, best_split = -1;
+        // (a large range: the bins of the three axes are filled piece by piece and merged; counts are integers and boxes
+        // are min/max, so the merged bins equal the ones a single sweep fills)
+        struct Bins { size_t cnt[3][NBINS]; Box bb[3][NBINS]; };
+        std::vector<Bins> piece_bins;
+        if (piecewise) {
+            piece_bins.resize(n_pieces);
+            each_piece(n_pieces, [&](size_t k) {
+                Bins& B = piece_bins[k];
+                for (int ax = 0; ax < 3; ++ax) {
+                    for (int b = 0; b < NBINS; ++b) B.cnt[ax][b] = 0;
+                    const double c0 = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
+                    if (!(ext > 0.0)) continue;
+                    const double scale = NBINS / ext;
+                    for (size_t i = first + k * PIECE; i < piece_end(k); ++i) {
+                        int b = (int)((cent[3 * idx[i] + ax] - c0) * scale);
+                        b = std::min(std::max(b, 0), NBINS - 1);
+                        B.cnt[ax][b]++;
+                        B.bb[ax][b].grow(pb[idx[i]].lo, pb[idx[i]].hi);
+                    }
+                }
+            });
+        }
         for (int ax = 0; ax < 3; ++ax) {
             double c0 = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
             if (!(ext > 0.0)) continue;
             size_t cnt[NBINS] = {0};
             Box bb[NBINS];
             double scale = NBINS / ext;
-            for (size_t i = first; i < first + count; ++i) {
-                int k = (int)((cent[3 * idx[i] + ax] - c0) * scale);
-                k = std::min(std::max(k, 0), NBINS - 1);
-                cnt[k]++;
-                bb[k].grow(pb[idx[i]].lo, pb[idx[i]].hi);
+            if (piecewise) {
+                for (size_t k = 0; k < n_pieces; ++k)
+                    for (int b = 0; b < NBINS; ++b) {
+                        cnt[b] += piece_bins[k].cnt[ax][b];
+                        if (piece_bins[k].cnt[ax][b]) bb[b].grow(piece_bins[k].bb[ax][b]);
+                    }
+            } else {
+                for (size_t i = first; i < first + count; ++i) {
+                    int k = (int)((cent[3 * idx[i] + ax] - c0) * scale);
+                    k = std::min(std::max(k, 0), NBINS - 1);
+                    cnt[k]++;
+                    bb[k].grow(pb[idx[i]].lo, pb[idx[i]].hi);
+                }
             }
             double right_area[NBINS];
             size_t right_cnt[NBINS];
@@ -171,12 +317,37 @@ struct Builder {
         size_t mid = first;
         if (best_axis >= 0) {
             double c0 = cb.lo[best_axis], scale = NBINS / (cb.hi[best_axis] - cb.lo[best_axis]);
-            auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t p) {
+            auto goes_left = [&](uint32_t p) {
                 int k = (int)((cent[3 * p + best_axis] - c0) * scale);
                 k = std::min(std::max(k, 0), NBINS - 1);
                 return k < best_split;
-            });
-            mid = (size_t)(it - idx.begin());
+            };
+            if (piecewise) {
+                // stable partition through the spare buffer: count per piece, place every piece's left and right run
+                // behind those of the pieces before it, copy back
+                std::vector<size_t> n_left(n_pieces + 1, 0);
+                each_piece(n_pieces, [&](size_t k) {
+                    size_t c = 0;
+                    for (size_t i = first + k * PIECE; i < piece_end(k); ++i) c += goes_left(idx[i]) ? 1 : 0;
+                    n_left[k + 1] = c;
+                });
+                for (size_t k = 0; k < n_pieces; ++k) n_left[k + 1] += n_left[k];      // lefts before piece k+1
+                const size_t all_left = n_left[n_pieces];
+                each_piece(n_pieces, [&](size_t k) {
+                    size_t l = first + n_left[k], r = first + all_left + (k * PIECE - n_left[k]);
+                    for (size_t i = first + k * PIECE; i < piece_end(k); ++i) {
+                        const uint32_t p = idx[i];
+                        if (goes_left(p)) spare[l++] = p; else spare[r++] = p;
+                    }
+                });
+                each_piece(n_pieces, [&](size_t k) {
+                    std::copy(spare.begin() + first + k * PIECE, spare.begin() + piece_end(k), idx.begin() + first + k * PIECE);
+                });
+                mid = first + all_left;
+            } else {
+                auto it = std::partition(idx.begin() + first, idx.begin() + first + count, goes_left);
+                mid = (size_t)(it - idx.begin());
+            }
         }
         size_t nl = mid - first, nr = count - nl;
         if (nl == 0 || nr == 0 || ceil_log2(nl) > remaining - 1 || ceil_log2(nr) > remaining - 1) {
@@ -233,6 +404,11 @@ static unsigned build_threads() {
     return std::max(1u, std::min(hw ? hw : 1u, 16u));
 }
 
+void for_each_piece(size_t n_pieces, const std::function<void(size_t)>& fn) {
+    Team crew(n_pieces > 1 ? build_threads() : 1u);
+    crew.run(n_pieces, fn);
+}
+
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out) {
     out = BvhResult();
     const size_t n = boxes.size();
@@ -240,7 +416,10 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
     out.nodes.reserve(n / 2 + 16);
     out.tri_order.reserve(n - n_spheres);
     out.sph_order.reserve(n_spheres);
-    Shared sh(boxes, n_spheres);
+    const unsigned T = build_threads();
+    const bool threaded = T > 1 && n >= 200000;
+    Team crew(threaded ? T : 1u);
+    Shared sh(boxes, n_spheres, crew);
     Builder B(sh, out);
     Box bounds;
     // Probe: would the whole scene be a single leaf?  Then wrap it so that node 0 always exists.
@@ -260,54 +439,63 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
         for (uint32_t& p : nd._pad) p = 0;
         return;
     }
-    const unsigned T = build_threads();
     std::vector<Task> tasks;
-    if (T > 1 && n >= 200000) {
+    if (threaded) {
         B.tasks = &tasks;
         B.task_threshold = std::max<size_t>(4096, n / ((size_t)T * 8));
+        B.team = &crew;             // the top of the tree: every large range is swept by the whole team
     }
     uint32_t root = B.build(0, n, 0, bounds);
     if (!tasks.empty()) {
-        // workers take tasks from a shared counter; every task writes only its own Task and its own idx range
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= tasks.size()) return;
-                Task& t = tasks[k];
-                t.result.nodes.reserve(t.count / 2 + 16);
-                Builder b(sh, t.result);
-                t.ref = b.build(t.first, t.count, t.depth, t.bounds);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned i = 1; i < T; ++i) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
-        // stitch in task order
-        for (Task& t : tasks) {
-            const uint32_t node_base = (uint32_t)out.nodes.size(), tri_base = (uint32_t)out.tri_order.size(),
-                           sph_base = (uint32_t)out.sph_order.size();
+        // the team takes the tasks from a shared counter; every task writes only its own Task and its own idx range
+        crew.run(tasks.size(), [&](size_t k) {
+            Task& t = tasks[k];
+            t.result.nodes.reserve(t.count / 2 + 16);
+            Builder b(sh, t.result);
+            t.ref = b.build(t.first, t.count, t.depth, t.bounds);
+        });
+        // stitch in task order: where every task's nodes and leaf orders go follows from the sizes, then the team copies
+        struct Base { size_t node, tri, sph; };
+        std::vector<Base> base(tasks.size() + 1);
+        base[0] = {out.nodes.size(), out.tri_order.size(), out.sph_order.size()};
+        for (size_t k = 0; k < tasks.size(); ++k)
+            base[k + 1] = {base[k].node + tasks[k].result.nodes.size(), base[k].tri + tasks[k].result.tri_order.size(),
+                           base[k].sph + tasks[k].result.sph_order.size()};
+        if (base.back().node >= (size_t)TASK_REF) { out = BvhResult(); return; }      // (cannot happen below 2^28 primitives)
+        out.nodes.resize(base.back().node);
+        out.tri_order.resize(base.back().tri);
+        out.sph_order.resize(base.back().sph);
+        crew.run(tasks.size(), [&](size_t k) {
+            Task& t = tasks[k];
+            const uint32_t node_base = (uint32_t)base[k].node, tri_base = (uint32_t)base[k].tri, sph_base = (uint32_t)base[k].sph;
             auto fix = [&](uint32_t ref) -> uint32_t {
                 if (ref == REF_EMPTY) return ref;
                 if (ref & REF_LEAF) return ref + ((ref & REF_SPHERE) ? sph_base : tri_base);     // `first` sits in the low bits
                 return ref + node_base;
             };
-            for (Node64 nd : t.result.nodes) {
+            Node64* dst = out.nodes.data() + base[k].node;
+            for (size_t i = 0; i < t.result.nodes.size(); ++i) {
+                Node64 nd = t.result.nodes[i];
                 nd.left = fix(nd.left);
                 nd.right = fix(nd.right);
-                out.nodes.push_back(nd);
+                dst[i] = nd;
             }
-            out.tri_order.insert(out.tri_order.end(), t.result.tri_order.begin(), t.result.tri_order.end());
-            out.sph_order.insert(out.sph_order.end(), t.result.sph_order.begin(), t.result.sph_order.end());
+            std::copy(t.result.tri_order.begin(), t.result.tri_order.end(), out.tri_order.begin() + base[k].tri);
+            std::copy(t.result.sph_order.begin(), t.result.sph_order.end(), out.sph_order.begin() + base[k].sph);
+            t.ref = fix(t.ref);
+            const uint32_t depth = t.result.depth, max_leaf = t.result.max_leaf;
+            t.result = BvhResult();
+            t.result.depth = depth;
+            t.result.max_leaf = max_leaf;
+        });
+        for (Task& t : tasks) {
             out.depth = std::max(out.depth, t.result.depth);
             out.max_leaf = std::max(out.max_leaf, t.result.max_leaf);
             Node64& par = out.nodes[t.parent];
             double* lo = t.side ? par.lo_r : par.lo_l;
             double* hi = t.side ? par.hi_r : par.hi_l;
             for (int k = 0; k < 3; ++k) { lo[k] = t.bounds.lo[k]; hi[k] = t.bounds.hi[k]; }
-            (t.side ? par.right : par.left) = fix(t.ref);
-            t.result = BvhResult();
+            (t.side ? par.right : par.left) = t.ref;
         }
     }
     if (root & REF_LEAF) {
@@ -324,29 +512,50 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
     }
 }
 
+// node arrays are converted in pieces of this many nodes, by the build threads when the array is large
+constexpr size_t NODE_PIECE = 32768;
+static unsigned node_threads(size_t n_nodes) { return n_nodes >= 4 * NODE_PIECE ? build_threads() : 1u; }
+
 void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out) {
     out.resize(in.size());
-    for (size_t i = 0; i < in.size(); ++i) {
-        const Node64& a = in[i];
-        Node32& b = out[i];
-        for (int k = 0; k < 3; ++k) {
-            b.lo_l[k] = round_down(a.lo_l[k]); b.hi_l[k] = round_up(a.hi_l[k]);
-            b.lo_r[k] = round_down(a.lo_r[k]); b.hi_r[k] = round_up(a.hi_r[k]);
+    Team crew(node_threads(in.size()));
+    crew.run(pieces_of(in.size(), NODE_PIECE), [&](size_t piece) {
+        for (size_t i = piece * NODE_PIECE; i < std::min(in.size(), (piece + 1) * NODE_PIECE); ++i) {
+            const Node64& a = in[i];
+            Node32& b = out[i];
+            for (int k = 0; k < 3; ++k) {
+                b.lo_l[k] = round_down(a.lo_l[k]); b.hi_l[k] = round_up(a.hi_l[k]);
+                b.lo_r[k] = round_down(a.lo_r[k]); b.hi_r[k] = round_up(a.hi_r[k]);
+            }
+            b.left = a.left;
+            b.right = a.right;
+            b._pad[0] = b._pad[1] = 0;
         }
-        b.left = a.left;
-        b.right = a.right;
-        b._pad[0] = b._pad[1] = 0;
-    }
+    });
 }
 
 bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, QuantGrid& g, double max_inflation) {
     if (in.empty()) return false;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (const Node32& n : in)
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = std::min(lo[k], n.lo_l[k]); hi[k] = std::max(hi[k], n.hi_l[k]);
-            if (n.right != REF_EMPTY) { lo[k] = std::min(lo[k], n.lo_r[k]); hi[k] = std::max(hi[k], n.hi_r[k]); }
-        }
+    const size_t n_pieces = pieces_of(in.size(), NODE_PIECE);
+    Team crew(node_threads(in.size()));
+    {
+        struct Ext { float lo[3], hi[3]; };
+        std::vector<Ext> part(n_pieces);
+        crew.run(n_pieces, [&](size_t piece) {
+            Ext e = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+            for (size_t i = piece * NODE_PIECE; i < std::min(in.size(), (piece + 1) * NODE_PIECE); ++i) {
+                const Node32& n = in[i];
+                for (int k = 0; k < 3; ++k) {
+                    e.lo[k] = std::min(e.lo[k], n.lo_l[k]); e.hi[k] = std::max(e.hi[k], n.hi_l[k]);
+                    if (n.right != REF_EMPTY) { e.lo[k] = std::min(e.lo[k], n.lo_r[k]); e.hi[k] = std::max(e.hi[k], n.hi_r[k]); }
+                }
+            }
+            part[piece] = e;
+        });
+        for (const Ext& e : part)
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], e.lo[k]); hi[k] = std::max(hi[k], e.hi[k]); }
+    }
     for (int k = 0; k < 3; ++k) {
         if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return false;
         g.origin[k] = lo[k];
@@ -373,30 +582,43 @@ bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, Qua
         return true;
     };
     std::vector<Node16> res(in.size());
-    double infl = 0.0;
-    size_t n_leaf = 0;
-    auto area = [](const float* l, const float* h, double pad[3]) {
+    auto area = [](const float* l, const float* h, const double pad[3]) {
         double e[3];
         for (int k = 0; k < 3; ++k) e[k] = (double)h[k] - (double)l[k] + 2.0 * pad[k];
         return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
     };
-    double pad0[3] = {0, 0, 0}, pad1[3] = {g.cell[0], g.cell[1], g.cell[2]};
-    for (size_t i = 0; i < in.size(); ++i) {
-        const Node32& a = in[i];
-        Node16& b = res[i];
-        const bool has_r = a.right != REF_EMPTY;
-        for (int k = 0; k < 3; ++k) {
-            if (!qlo(a.lo_l[k], k, b.lo_l[k]) || !qhi(a.hi_l[k], k, b.hi_l[k])) return false;
-            if (has_r) {
-                if (!qlo(a.lo_r[k], k, b.lo_r[k]) || !qhi(a.hi_r[k], k, b.hi_r[k])) return false;
-            } else {
-                b.lo_r[k] = 65535; b.hi_r[k] = 0;
+    const double pad0[3] = {0, 0, 0}, pad1[3] = {g.cell[0], g.cell[1], g.cell[2]};
+    // per piece: the inflation sum of its leaf boxes, their number, and whether every plane could be placed; the sums
+    // are added up in piece order, so the decision below does not depend on the thread count
+    struct Part { double infl; size_t n_leaf; bool ok; };
+    std::vector<Part> part(n_pieces);
+    crew.run(n_pieces, [&](size_t piece) {
+        Part pt = {0.0, 0, true};
+        for (size_t i = piece * NODE_PIECE; i < std::min(in.size(), (piece + 1) * NODE_PIECE) && pt.ok; ++i) {
+            const Node32& a = in[i];
+            Node16& b = res[i];
+            const bool has_r = a.right != REF_EMPTY;
+            for (int k = 0; k < 3 && pt.ok; ++k) {
+                if (!qlo(a.lo_l[k], k, b.lo_l[k]) || !qhi(a.hi_l[k], k, b.hi_l[k])) pt.ok = false;
+                if (has_r) {
+                    if (!qlo(a.lo_r[k], k, b.lo_r[k]) || !qhi(a.hi_r[k], k, b.hi_r[k])) pt.ok = false;
+                } else {
+                    b.lo_r[k] = 65535; b.hi_r[k] = 0;
+                }
             }
+            b.left = a.left;
+            b.right = a.right;
+            if (a.left & REF_LEAF) { double s0 = area(a.lo_l, a.hi_l, pad0); if (s0 > 0) { pt.infl += area(a.lo_l, a.hi_l, pad1) / s0; ++pt.n_leaf; } }
+            if (has_r && (a.right & REF_LEAF)) { double s0 = area(a.lo_r, a.hi_r, pad0); if (s0 > 0) { pt.infl += area(a.lo_r, a.hi_r, pad1) / s0; ++pt.n_leaf; } }
         }
-        b.left = a.left;
-        b.right = a.right;
-        if (a.left & REF_LEAF) { double s0 = area(a.lo_l, a.hi_l, pad0); if (s0 > 0) { infl += area(a.lo_l, a.hi_l, pad1) / s0; ++n_leaf; } }
-        if (has_r && (a.right & REF_LEAF)) { double s0 = area(a.lo_r, a.hi_r, pad0); if (s0 > 0) { infl += area(a.lo_r, a.hi_r, pad1) / s0; ++n_leaf; } }
+        part[piece] = pt;
+    });
+    double infl = 0.0;
+    size_t n_leaf = 0;
+    for (const Part& pt : part) {
+        if (!pt.ok) return false;
+        infl += pt.infl;
+        n_leaf += pt.n_leaf;
     }
     if (n_leaf && infl / (double)n_leaf > max_inflation) return false;
     out.swap(res);
@@ -443,9 +665,9 @@ struct Wide {
             ++c;
         }
     }
-    // emits the BVH4 node that replaces BVH2 node n2; returns its stack need
-    uint32_t emit(uint32_t n2, uint32_t& index) {
-        Ent e[5];
+    // the children of the BVH4 node that replaces BVH2 node n2: its own two, then the grandchildren with the largest
+    // boxes pulled up until there are four
+    int collapse(uint32_t n2, Ent* e) const {
         int c = 0;
         children(in[n2], e, c);
         while (c < 4) {
@@ -460,17 +682,58 @@ struct Wide {
             e[best] = sub[0];
             if (cs == 2) e[c++] = sub[1];
         }
-        index = (uint32_t)out.size();
-        out.emplace_back();
-        uint32_t refs[4] = {REF_EMPTY, REF_EMPTY, REF_EMPTY, REF_EMPTY}, deepest = 0;
+        return c;
+    }
+    // number of BVH4 nodes the subtree of n2 becomes
+    size_t count(uint32_t n2) const {
+        Ent e[5];
+        const int c = collapse(n2, e);
+        size_t k = 1;
+        for (int i = 0; i < c; ++i)
+            if (!(e[i].ref & REF_LEAF)) k += count(e[i].ref);
+        return k;
+    }
+    // Emits the BVH4 subtree that replaces BVH2 node n2 into out[cursor...] in pre-order (a node, then the subtrees of
+    // its children one after the other); out is sized beforehand.
+    void emit(uint32_t n2, uint32_t& cursor) {
+        Ent e[5];
+        const int c = collapse(n2, e);
+        const uint32_t index = cursor++;
+        uint32_t refs[4] = {REF_EMPTY, REF_EMPTY, REF_EMPTY, REF_EMPTY};
         for (int i = 0; i < c; ++i) {
             if (e[i].ref & REF_LEAF) { refs[i] = e[i].ref; continue; }
-            uint32_t ci = 0;
-            deepest = std::max(deepest, emit(e[i].ref, ci));
-            refs[i] = ci;
+            refs[i] = cursor;
+            emit(e[i].ref, cursor);
         }
         store(out[index], e, c, refs);
-        return (uint32_t)(c - 1) + deepest;
+    }
+    // The subtrees that hang `levels` BVH4 levels below n2, in the order emit reaches them.
+    void frontier(uint32_t n2, int levels, std::vector<uint32_t>& roots) const {
+        if (levels == 0) { roots.push_back(n2); return; }
+        Ent e[5];
+        const int c = collapse(n2, e);
+        for (int i = 0; i < c; ++i)
+            if (!(e[i].ref & REF_LEAF)) frontier(e[i].ref, levels - 1, roots);
+    }
+    // emit for the nodes above the frontier: same order, the frontier subtrees only get their place (base[k], sizes
+    // size[k], consumed in order through `next`)
+    void emit_top(uint32_t n2, int levels, uint32_t& cursor, const std::vector<size_t>& size, std::vector<uint32_t>& base, size_t& next) {
+        if (levels == 0) {
+            base[next] = cursor;
+            cursor += (uint32_t)size[next];
+            ++next;
+            return;
+        }
+        Ent e[5];
+        const int c = collapse(n2, e);
+        const uint32_t index = cursor++;
+        uint32_t refs[4] = {REF_EMPTY, REF_EMPTY, REF_EMPTY, REF_EMPTY};
+        for (int i = 0; i < c; ++i) {
+            if (e[i].ref & REF_LEAF) { refs[i] = e[i].ref; continue; }
+            refs[i] = cursor;
+            emit_top(e[i].ref, levels - 1, cursor, size, base, next);
+        }
+        store(out[index], e, c, refs);
     }
     void store(Node4& nd, const Ent* e, int c, const uint32_t* refs) {
         for (int i = 0; i < 4; ++i) {
@@ -494,29 +757,68 @@ struct Wide {
 };
 }  // namespace
 
-bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<Node4>& out, uint32_t& stack_need) {
+namespace {
+// BVH2 -> BVH4 for either node format.  The subtrees a few levels below the root are counted, then emitted, by the
+// build threads side by side; where each lands follows from the counts, so the result is the pre-order numbering a
+// single depth-first emit produces, whatever the thread count.
+template <class NodeT>
+bool widen_any(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<NodeT>& out, uint32_t& stack_need) {
     if (in.empty()) return false;
-    std::vector<Node4> res;
-    res.reserve(in.size() / 2 + 16);
-    Wide<Node4> w{in, grid, res};
-    uint32_t root = 0;
-    stack_need = w.emit(0, root);
-    if (!w.ok || root != 0) return false;
+    std::vector<NodeT> res;
+    Wide<NodeT> top{in, grid, res};
+    const unsigned T = build_threads();
+    const int levels = (T > 1 && in.size() >= 100000) ? 4 : 0;
+    std::vector<uint32_t> roots;
+    top.frontier(0, levels, roots);
+    std::vector<size_t> size(roots.size());
+    std::vector<uint32_t> base(roots.size());
+    Team crew(levels ? T : 1u);
+    crew.run(roots.size(), [&](size_t k) { size[k] = top.count(roots[k]); });
+    size_t total = 0;
+    for (size_t k = 0; k < roots.size(); ++k) total += size[k];
+    total += 1024;                                  // the nodes above the frontier: at most 1 + 4 + 16 + 64
+    if (total >= (size_t)REF_FIRST_MASK) return false;
+    res.resize(total);
+    uint32_t cursor = 0;
+    size_t next = 0;
+    top.emit_top(0, levels, cursor, size, base, next);
+    res.resize(cursor);
+    std::vector<char> bad(roots.size(), 0);
+    crew.run(roots.size(), [&](size_t k) {
+        Wide<NodeT> w{in, grid, res};
+        uint32_t c = base[k];
+        w.emit(roots[k], c);
+        bad[k] = (!w.ok || c != base[k] + size[k]) ? 1 : 0;
+    });
+    if (!top.ok) return false;
+    for (char f : bad)
+        if (f) return false;
+    // stack need of a near-first traversal that pushes every other hit child: children sit behind their parent, so one
+    // backward sweep has every child's need before its parent's
+    std::vector<uint8_t> need(res.size(), 0);
+    for (size_t i = res.size(); i-- > 0;) {
+        uint32_t c = 0, deepest = 0;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ref = res[i].child[k];
+            if (ref == REF_EMPTY) continue;
+            ++c;
+            if (!(ref & REF_LEAF)) deepest = std::max<uint32_t>(deepest, need[ref]);
+        }
+        need[i] = (uint8_t)std::min<uint32_t>(255u, (c ? c - 1 : 0) + deepest);
+    }
+    stack_need = need[0];
     out.swap(res);
     return true;
 }
+}  // namespace
+
+bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<Node4>& out, uint32_t& stack_need) {
+    return widen_any(in, grid, out, stack_need);
+}
 
 bool widen_nodes_f32(const std::vector<Node64>& in, std::vector<Node4f>& out, uint32_t& stack_need) {
-    if (in.empty()) return false;
-    std::vector<Node4f> res;
-    res.reserve(in.size() / 2 + 16);
     const QuantGrid none{};
-    Wide<Node4f> w{in, none, res};
-    uint32_t root = 0;
-    stack_need = w.emit(0, root);
-    if (root != 0) return false;
-    out.swap(res);
-    return true;
+    return widen_any(in, none, out, stack_need);
 }
 
 }  // namespace rt

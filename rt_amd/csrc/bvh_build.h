@@ -1,8 +1,11 @@
 // bvh_build.h — host BVH builder for the flattened scene (replaces bvh::Bvh::build_par, which the
 // reference calls at src/hittable.rs:34).  Binned SAH, BVH2 with child boxes in the parent,
-// homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= SAH_MAX_DEPTH.
+// homogeneous leaves of <= MAX_LEAF primitives, child-reference depth <= SAH_MAX_DEPTH.  Threaded (the top of the
+// tree by all threads together, the subtrees below side by side; node-format conversions in pieces); the tree and
+// the order of the primitives in its leaves do not depend on the number of threads.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -21,6 +24,10 @@ struct BvhResult {
     uint32_t depth = 0;                 // deepest child reference
     uint32_t max_leaf = 0;
 };
+
+// fn(k) once for every k in [0, n_pieces), on the build threads (RT_HIP_BUILD_THREADS, default min(cores, 16)) and the
+// caller; returns when all calls have returned.  The builder and the flattening loops of rt_scene_create share it.
+void for_each_piece(size_t n_pieces, const std::function<void(size_t)>& fn);
 
 // boxes: first n_spheres entries are spheres, the rest triangles (the caller's primitive order).
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out);

@@ -887,10 +887,22 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         if (!finite3(spheres[i].center) || !std::isfinite(spheres[i].radius) || spheres[i].radius < 0.0)
             return fail(RT_ERR_INVALID, "sphere %zu: non-finite or negative geometry", i);
     }
-    for (size_t i = 0; i < n_triangles; ++i) {
-        if (triangles[i].material >= n_materials) return fail(RT_ERR_INVALID, "triangle %zu: material out of range", i);
-        if (!finite3(triangles[i].a) || !finite3(triangles[i].b) || !finite3(triangles[i].c))
+    {   // (in pieces on the build threads; the first offending triangle is the one reported, as a plain loop would)
+        constexpr size_t PIECE = 65536;
+        const size_t n_pieces = (n_triangles + PIECE - 1) / PIECE;
+        std::vector<size_t> first_bad(n_pieces, SIZE_MAX);
+        for_each_piece(n_pieces, [&](size_t piece) {
+            for (size_t i = piece * PIECE; i < std::min(n_triangles, (piece + 1) * PIECE); ++i)
+                if (triangles[i].material >= n_materials || !finite3(triangles[i].a) || !finite3(triangles[i].b) || !finite3(triangles[i].c)) {
+                    first_bad[piece] = i;
+                    break;
+                }
+        });
+        for (size_t i : first_bad) {
+            if (i == SIZE_MAX) continue;
+            if (triangles[i].material >= n_materials) return fail(RT_ERR_INVALID, "triangle %zu: material out of range", i);
             return fail(RT_ERR_INVALID, "triangle %zu: non-finite vertex", i);
+        }
     }
     DeviceGuard dg;
     int rc = select_device(device);
@@ -918,13 +930,22 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                 boxes[i].lo[k] = spheres[i].center[k] - spheres[i].radius;
                 boxes[i].hi[k] = spheres[i].center[k] + spheres[i].radius;
             }
-        for (size_t i = 0; i < n_triangles; ++i) {
-            const rt_triangle& t = triangles[i];
-            for (int k = 0; k < 3; ++k) {
-                boxes[n_spheres + i].lo[k] = std::min(std::min(t.a[k], t.b[k]), t.c[k]);
-                boxes[n_spheres + i].hi[k] = std::max(std::max(t.a[k], t.b[k]), t.c[k]);
+        // (the per-triangle loops of this function run in pieces on the build threads: at 20 M triangles they were a
+        // third of the time to the first pixel)
+        constexpr size_t TRI_PIECE = 65536;
+        const size_t tri_pieces = (n_triangles + TRI_PIECE - 1) / TRI_PIECE;
+        auto tri_piece = [&](size_t piece, size_t& i0, size_t& i1) { i0 = piece * TRI_PIECE; i1 = std::min(n_triangles, i0 + TRI_PIECE); };
+        for_each_piece(tri_pieces, [&](size_t piece) {
+            size_t i0, i1;
+            tri_piece(piece, i0, i1);
+            for (size_t i = i0; i < i1; ++i) {
+                const rt_triangle& t = triangles[i];
+                for (int k = 0; k < 3; ++k) {
+                    boxes[n_spheres + i].lo[k] = std::min(std::min(t.a[k], t.b[k]), t.c[k]);
+                    boxes[n_spheres + i].hi[k] = std::max(std::max(t.a[k], t.b[k]), t.c[k]);
+                }
             }
-        }
+        });
         BvhResult bvh;
         // RT_HIP_BUILDER=lbvh: Morton-order build on the device (milliseconds; lower tree quality); default: binned SAH
         // on the host.  The device build declines tiny scenes and trees deeper than the traversal stacks.
@@ -947,30 +968,34 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
 
         // ---- flatten
         std::vector<TriGeom> tg(n_triangles);
-        for (size_t k = 0; k < n_triangles; ++k) {
-            const rt_triangle& t = triangles[bvh.tri_order[k]];
-            for (int c = 0; c < 3; ++c) {
-                tg[k].a[c] = t.a[c];
-                tg[k].e1[c] = t.b[c] - t.a[c];           // a_to_b (src/hittable.rs:412)
-                tg[k].e2[c] = t.c[c] - t.a[c];           // a_to_c (:413)
-            }
-            tg[k].prim = (uint32_t)(n_spheres + bvh.tri_order[k]);
-            tg[k]._pad = 0;
-        }
         std::vector<TriShade> tsh(n_triangles);
-        for (size_t i = 0; i < n_triangles; ++i) {
-            const rt_triangle& t = triangles[i];
-            for (int c = 0; c < 3; ++c) tsh[i].n[c] = t.n[c];
-            // f64::min/max chain (src/hittable.rs:469-476)
-            const double left = std::fmin(std::fmin(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
-            const double right = std::fmax(std::fmax(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
-            const double bot = std::fmin(std::fmin(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
-            const double top = std::fmax(std::fmax(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
-            tsh[i].uv_left = left; tsh[i].uv_width = right - left;
-            tsh[i].uv_bot = bot; tsh[i].uv_height = top - bot;
-            tsh[i].material = t.material;
-            tsh[i]._pad = 0;
-        }
+        for_each_piece(tri_pieces, [&](size_t piece) {
+            size_t i0, i1;
+            tri_piece(piece, i0, i1);
+            for (size_t k = i0; k < i1; ++k) {
+                const rt_triangle& t = triangles[bvh.tri_order[k]];
+                for (int c = 0; c < 3; ++c) {
+                    tg[k].a[c] = t.a[c];
+                    tg[k].e1[c] = t.b[c] - t.a[c];           // a_to_b (src/hittable.rs:412)
+                    tg[k].e2[c] = t.c[c] - t.a[c];           // a_to_c (:413)
+                }
+                tg[k].prim = (uint32_t)(n_spheres + bvh.tri_order[k]);
+                tg[k]._pad = 0;
+            }
+            for (size_t i = i0; i < i1; ++i) {
+                const rt_triangle& t = triangles[i];
+                for (int c = 0; c < 3; ++c) tsh[i].n[c] = t.n[c];
+                // f64::min/max chain (src/hittable.rs:469-476)
+                const double left = std::fmin(std::fmin(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
+                const double right = std::fmax(std::fmax(t.uv[0][0], t.uv[1][0]), t.uv[2][0]);
+                const double bot = std::fmin(std::fmin(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
+                const double top = std::fmax(std::fmax(t.uv[0][1], t.uv[1][1]), t.uv[2][1]);
+                tsh[i].uv_left = left; tsh[i].uv_width = right - left;
+                tsh[i].uv_bot = bot; tsh[i].uv_height = top - bot;
+                tsh[i].material = t.material;
+                tsh[i]._pad = 0;
+            }
+        });
         std::vector<SphShade> ssh(n_spheres);
         for (size_t i = 0; i < n_spheres; ++i) {
             const rt_sphere& s = spheres[i];

@@ -4,6 +4,7 @@
 // Compiled by tests/test_bvh_host.py with g++ -fsanitize=address,undefined (no GPU, no HIP).
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -51,11 +52,16 @@ static B3 walk(const BvhResult& r, const std::vector<PrimBox>& boxes, size_t n_s
 
 static size_t last_nodes = 0;
 static uint32_t last_depth = 0;
+static std::vector<uint32_t> last_tri_order, last_sph_order;
+static std::vector<Node4> last_n4;
 static void check_tree(const char* what, const std::vector<PrimBox>& boxes, size_t n_spheres) {
     BvhResult r;
     build_bvh(boxes, n_spheres, r);
     last_nodes = r.nodes.size();
     last_depth = r.depth;
+    last_tri_order = r.tri_order;
+    last_sph_order = r.sph_order;
+    last_n4.clear();
     std::vector<int> seen(boxes.size(), 0);
     uint32_t max_depth = 0;
     if (!boxes.empty()) walk(r, boxes, n_spheres, 0, 0, seen, max_depth);
@@ -93,6 +99,7 @@ static void check_tree(const char* what, const std::vector<PrimBox>& boxes, size
             }
         CHECK(leaves == boxes.size(), "%s: BVH4 holds %zu of %zu primitives", what, leaves, boxes.size());
         CHECK(need <= 3u * (r.depth + 1), "%s: BVH4 stack need %u", what, need);
+        last_n4 = n4;
     }
     std::vector<Node4f> n4f;
     uint32_t need_f = 0;
@@ -123,9 +130,20 @@ int main() {
     check_tree("mixed 300k (4 threads)", big, 20000);
     const size_t nodes4 = last_nodes;
     const uint32_t depth4 = last_depth;
+    const std::vector<uint32_t> tri4 = last_tri_order, sph4 = last_sph_order;
+    const std::vector<Node4> wide4 = last_n4;
     setenv("RT_HIP_BUILD_THREADS", "1", 1);
     check_tree("mixed 300k (1 thread)", big, 20000);
     CHECK(nodes4 == last_nodes && depth4 == last_depth, "threaded build differs from the sequential one: %zu/%u vs %zu/%u", nodes4, depth4, last_nodes, last_depth);
+    // the same tree whatever the thread count: the primitives sit in the leaves in the same order, and the BVH4 (numbered
+    // in pre-order from the topology alone) is the same array byte for byte
+    CHECK(tri4 == last_tri_order && sph4 == last_sph_order, "leaf order depends on the thread count");
+    CHECK(!wide4.empty() && wide4.size() == last_n4.size() && memcmp(wide4.data(), last_n4.data(), wide4.size() * sizeof(Node4)) == 0,
+          "BVH4 depends on the thread count (%zu vs %zu nodes)", wide4.size(), last_n4.size());
+    setenv("RT_HIP_BUILD_THREADS", "7", 1);
+    check_tree("mixed 300k (7 threads)", big, 20000);
+    CHECK(tri4 == last_tri_order && wide4.size() == last_n4.size() && memcmp(wide4.data(), last_n4.data(), wide4.size() * sizeof(Node4)) == 0,
+          "7-thread build differs from the 4-thread one");
     printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
     return fails ? 1 : 0;
 }
