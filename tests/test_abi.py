@@ -55,6 +55,29 @@ def test_invalid_arguments_are_rejected_before_touching_the_gpu():
     assert L.rt_trace_closest(None, None, 0, 0.0, 1.0, None, None) == _abi.RT_ERR_INVALID
 
 
+def test_triangle_checks_report_the_first_offender_from_any_piece():
+    """rt_scene_create validates triangles in pieces on the build threads: the triangle named in the message is the first
+    bad one in the caller's order (what a plain loop reports), not whichever piece finished first."""
+    L = _lib.lib()
+    sky = _abi.one(_abi.sky_dt)
+    h = C.c_void_p()
+    n = 300_000                                     # several pieces of 65536
+    tris = np.zeros(n, dtype=_abi.triangle_dt)
+    tris["b"][:, 0] = 1.0
+    tris["c"][:, 1] = 1.0
+    mats = np.zeros(1, dtype=_abi.material_dt)
+    mats["kind"] = 2                                # dielectric: needs no texture
+    for bad, field in ((250_001, "material"), (70_000, "vertex")):
+        if field == "material":
+            tris["material"][bad] = 7
+        else:
+            tris["a"][bad, 2] = np.nan
+        rc = L.rt_scene_create(None, 0, _abi.ptr(tris), n, _abi.ptr(mats), 1, None, 0, None, 0, _abi.ptr(sky), 0, C.byref(h))
+        assert rc == _abi.RT_ERR_INVALID and not h.value
+        msg = L.rt_last_error()
+        assert (b"triangle %d:" % bad) in msg and (b"material" if field == "material" else b"non-finite") in msg, msg
+
+
 def test_no_device_is_an_error_not_a_fallback():
     L = _lib.lib()
     n = C.c_int(-1)
