@@ -3,6 +3,8 @@ draws the scene (sphere count, mesh resolution: all material and texture kinds o
 field of view, defocus disc or pinhole, frame sizes that are not multiples of the 8x8 camera tile), samples per pixel,
 depth limit and RNG seed from one integer, so a failure names the case that reproduces it.  Bar as in test_gpu_parity.py:
 closest hits bit-exact, equal segment counts, radiance within 2e-6 (f32 sky transcendentals)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,17 +16,17 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 2e-6, 1e-12
 
 
-def draw_case(case):
-    g = np.random.default_rng(1000 + case)
-    n_spheres = int(g.integers(0, 61))
-    quads = int(g.integers(2, 17))
+def draw_case(case, large=False):
+    g = np.random.default_rng((5000 if large else 1000) + case)
+    n_spheres = int(g.integers(300, 2001)) if large else int(g.integers(0, 61))
+    quads = int(g.integers(24, 65)) if large else int(g.integers(2, 17))
     ang, rad = g.uniform(0, 2 * np.pi), g.uniform(5.0, 14.0)
     look_from = (float(rad * np.cos(ang)), float(rad * np.sin(ang)), float(g.uniform(0.4, 8.0)))
     look_at = (float(g.uniform(-2, 2)), float(g.uniform(-2, 2)), float(g.uniform(0.0, 1.5)))
     focus = float(g.uniform(4.0, 15.0))
     defocus = float(g.choice([0.0, 0.0, 0.2, 1.0]))
     width, height = int(g.integers(33, 101)), int(g.integers(17, 71))
-    spp = int(g.integers(1, 6))
+    spp = int(g.integers(1, 3)) if large else int(g.integers(1, 6))
     max_depth = int(g.choice([1, 2, 7, 50]))
     vfov = float(g.uniform(15.0, 70.0))
     seed = int(g.integers(0, 2**31))
@@ -41,7 +43,8 @@ def random_rays(n, seed):
     return np.concatenate([o, d], -1)
 
 
-@pytest.mark.parametrize("case", range(24))
+# RT_FUZZ_CASES=<n> widens the sweep (400 cases were run once on the final round-2 build: all equal)
+@pytest.mark.parametrize("case", range(int(os.environ.get("RT_FUZZ_CASES", "24"))))
 def test_random_scene_and_camera_match_oracle(oracle, case):
     c = draw_case(case)
     desc = scenes.mixed_test_scene(seed=c["scene_seed"], n_spheres=c["n_spheres"], quads=c["quads"])
@@ -56,6 +59,28 @@ def test_random_scene_and_camera_match_oracle(oracle, case):
         img, st = cam.render_image(world, spp=c["spp"], seed=c["seed"], with_stats=True)
         want, rst = orc.render(cam, c["spp"], seed=c["seed"], mode=oracle.BRUTE, with_stats=True)
         assert int(st["samples"]) == c["width"] * c["height"] * c["spp"], c
+        assert int(st["ray_segments"]) == int(rst["ray_segments"]), c
+        np.testing.assert_allclose(img, want, rtol=RTOL, atol=ATOL, err_msg=str(c))
+    finally:
+        orc.close()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_larger_scenes_match_oracle(oracle, case):
+    """The same sweep over scenes of a few thousand primitives (300-2000 overlapping spheres, meshes of up to 8192
+    triangles): trees deep enough for every stack and leaf path of the walk; the oracle renders through its own BVH."""
+    c = draw_case(case, large=True)
+    desc = scenes.mixed_test_scene(seed=c["scene_seed"], n_spheres=c["n_spheres"], quads=c["quads"])
+    world, orc = World.build(desc), oracle.OracleScene(desc)
+    try:
+        rays = random_rays(3000, c["seed"] ^ 0x77)
+        gpu, ref = world.hit(rays), orc.hit(rays, mode=oracle.BRUTE)
+        bad = np.flatnonzero((gpu["prim"] != ref["prim"]) | (gpu["t"] != ref["t"]))
+        assert bad.size == 0, f"case {c}: {bad.size} closest hits differ, first gpu={gpu[bad[:2]]} ref={ref[bad[:2]]}"
+        cam = Camera.new(c["look_from"], c["look_at"], (0.0, 0.0, 1.0), c["focus"], c["defocus"], c["width"], c["height"],
+                         c["spp"], c["max_depth"], c["vfov"])
+        img, st = cam.render_image(world, spp=c["spp"], seed=c["seed"], with_stats=True)
+        want, rst = orc.render(cam, c["spp"], seed=c["seed"], mode=oracle.BVH_PRUNE, with_stats=True)
         assert int(st["ray_segments"]) == int(rst["ray_segments"]), c
         np.testing.assert_allclose(img, want, rtol=RTOL, atol=ATOL, err_msg=str(c))
     finally:
