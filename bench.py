@@ -227,6 +227,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    # RT_BENCH_EXTRA_STREAMS=<n> (A/B only): n used streams in the process before the library makes its own, as a host with
+    # its own copy / collective streams would have; the library's stream set-up must make the frame rate independent of n
+    extra_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("RT_BENCH_EXTRA_STREAMS", "0")))]
+    for es in extra_streams:
+        with torch.cuda.stream(es):
+            torch.zeros(16, device="cuda")
     from rt_amd import World, _abi
     from rt_amd._lib import check, lib
 
@@ -248,18 +254,31 @@ def main():
 
     from rt_amd.distributed import hip_render_sum, hip_resolve, render_distributed
 
+    # With more than one rank the exchange step of a frame (RCCL sum-reduce over xGMI + rank 0's resolve) is queued on a
+    # side stream, so the next frame's kernels do not wait for the collective: two sum buffers alternate, an event per
+    # buffer says when its exchange is over.  Everything is complete inside the timed region (barrier() synchronises the
+    # device).  One rank: no exchange, the frame is resolved in place.
+    side = torch.cuda.Stream() if use_dist else None
+    sums = [rgb_sum, torch.zeros_like(rgb_sum)] if use_dist else [rgb_sum]
+    exchanged = [None] * len(sums)
+    last = {"k": 0, "mean": None}
+
     def step(collect=False, spp_override=None):
         """One pass of the hot path: render this rank's sample indices, RCCL sum-reduce, resolve."""
-        box = {}
-
         def render_sum(n_spp, offset, stride, seed, out_sum):
-            box["st"] = hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect)
-            return box["st"]
+            return hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect)
 
-        mean, st = render_distributed(render_sum, rgb_sum, spp_override or spp, seed=2024,
-                                      resolve=lambda s, total: hip_resolve(s, total, local_rank))
+        b = last["k"] % len(sums)
+        last["k"] += 1
+        if exchanged[b] is not None:
+            torch.cuda.current_stream().wait_event(exchanged[b])      # the frame before last has left this buffer
+        mean, st = render_distributed(render_sum, sums[b], spp_override or spp, seed=2024,
+                                      resolve=lambda s, total: hip_resolve(s, total, local_rank), side_stream=side)
+        if side is not None:
+            exchanged[b] = torch.cuda.Event()
+            exchanged[b].record(side)
         if mean is not None:
-            rgb_mean.copy_(mean)
+            last["mean"] = mean
         return st
 
     for _ in range(args.warmup):
@@ -293,6 +312,7 @@ def main():
         # visits per segment from an instrumented low-spp render of the same frame, and the kernels' durations
         # with one pass in flight (RT_HIP_PIPES=1), i.e. without other passes sharing the GPU
         scratch = torch.zeros_like(rgb_sum)
+        rgb_mean.copy_(last["mean"])                 # (the device is synchronised: the last frame's exchange is over)
         img = rgb_mean.cpu().numpy()
         sst = hip_render_sum(w._h, cam, min(spp, 4), 0, 1, 2024, scratch, local_rank, True)
         torch.cuda.synchronize()

@@ -136,7 +136,9 @@ struct rt_scene {
     std::mutex mu;
     bool device_built = false;       // BVH from bvh_gpu.hip
     Workspace ws[MAX_PIPES];         // one per in-flight pass (DEFAULT_PIPES passes are pipelined by default)
-    hipStream_t aux_stream[MAX_PIPES] = {};      // [0] unused: pipe 0 runs on the caller's stream
+    hipStream_t aux_stream[MAX_PIPES] = {};      // the pipes' streams when several passes are in flight (ensure_pipe_streams)
+    int n_aux = 0;                               // how many of them exist
+    hipStream_t pad_stream[3] = {};              // idle streams that only shift where HIP puts the pipes' streams (same place)
     hipEvent_t ev_fork = nullptr, ev_acc[MAX_PIPES] = {}, ev_cam[MAX_PIPES] = {};
     // grow-only device buffers for the host-facing entry points (the frame of rt_render, the ray / hit staging of
     // rt_trace_closest and rt_trace_primary): no hipMalloc / hipFree per call once they have their size
@@ -317,6 +319,75 @@ int env_int(const char* name, int dflt) {
     return e && *e ? atoi(e) : dflt;
 }
 
+// ---- streams of the passes in flight ---------------------------------------------------------------------------------
+// A HIP process has GPU_MAX_HW_QUEUES hardware queues (4 here) and every stream is put on the one that carries the fewest
+// streams at that moment: four streams made in a row sit on four different queues only if the streams the host made
+// before (the null stream, torch's RCCL stream, a side stream for copies ...) were spread evenly.  Two pipes on one queue
+// run one after the other, and a 256-spp frame takes 4-11 % longer (measured: 71.4 ms with 4 or 8 streams in the process,
+// 76.5 / 80.6 / 74.5 ms with 5 / 6 / 7).  So the set-up checks: one wave per pipe stream waits PROBE_US; side by side all are
+// done after about PROBE_US, with two of them on one queue after twice that.  When they are not side by side, one more
+// idle stream is parked (at most three: with the fourth the count is even again) and the pipes' streams are made anew.
+constexpr unsigned PROBE_US = 200;
+__global__ void k_stream_probe(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 18); ++i) {            // bounded whatever the clock does (s_sleep 8 = 512 cycles a turn)
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+int pipes_side_by_side(rt_scene* sc, int n, bool* ok) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, sc->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    const unsigned long long ticks = (unsigned long long)khz * PROBE_US / 1000ull;
+    hipEvent_t start = nullptr, end[MAX_PIPES] = {};
+    HIPCHK(hipEventCreate(&start));
+    for (int k = 0; k < n; ++k) HIPCHK(hipEventCreate(&end[k]));
+    float worst = 0.f;
+    for (int round = 0; round < 2; ++round) {        // the first round only warms the streams up (queue creation, code load)
+        HIPCHK(hipEventRecord(start, sc->aux_stream[0]));
+        for (int k = 0; k < n; ++k) {
+            hipLaunchKernelGGL(k_stream_probe, dim3(1), dim3(64), 0, sc->aux_stream[k], ticks);
+            HIPCHK(hipEventRecord(end[k], sc->aux_stream[k]));
+        }
+        for (int k = 0; k < n; ++k) HIPCHK(hipStreamSynchronize(sc->aux_stream[k]));
+        worst = 0.f;
+        for (int k = 0; k < n; ++k) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, start, end[k]));
+            worst = std::max(worst, ms);
+        }
+    }
+    (void)hipEventDestroy(start);
+    for (int k = 0; k < n; ++k) (void)hipEventDestroy(end[k]);
+    *ok = worst < 1.6f * (float)PROBE_US * 1e-3f;
+    if (getenv("RT_HIP_DEBUG_UTIL")) fprintf(stderr, "[rt_hip] %d pipe streams: probe waves done after %.0f us (%s)\n", n, worst * 1e3f, *ok ? "side by side" : "queued behind each other");
+    return RT_OK;
+}
+
+int ensure_pipe_streams(rt_scene* sc, int n_pipes) {
+    if (n_pipes <= 1 || sc->n_aux >= n_pipes) return RT_OK;
+    auto drop = [&]() {
+        for (int k = 0; k < sc->n_aux; ++k)
+            if (sc->aux_stream[k]) { (void)hipStreamDestroy(sc->aux_stream[k]); sc->aux_stream[k] = nullptr; }
+        sc->n_aux = 0;
+    };
+    drop();                                          // (no pass is in flight here: the caller holds the scene)
+    const int hw_queues = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
+    const bool probe = n_pipes <= hw_queues && env_int("RT_HIP_STREAM_PROBE", 1) != 0;
+    for (int attempt = 0;; ++attempt) {
+        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
+        sc->n_aux = n_pipes;
+        if (!probe || attempt == 3) return RT_OK;
+        bool ok = false;
+        int rc = pipes_side_by_side(sc, n_pipes, &ok);
+        if (rc) return rc;
+        if (ok) return RT_OK;
+        drop();
+        HIPCHK(hipStreamCreateWithFlags(&sc->pad_stream[attempt], hipStreamNonBlocking));
+    }
+}
+
 int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
                          rt_stats* stats, uint32_t per_pass, uint32_t n_passes, int n_pipes, const PassParams& pp0, uint32_t group_cap);
 
@@ -404,8 +475,10 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     }
     // (One stream per pass in flight and no more: beyond four hardware queues per process the queues are time-sliced on
     // this platform and a render stalls for seconds, so the short phases of a pass get no high-priority side stream.)
-    for (int k = 1; k < n_pipes; ++k)
-        if (!sc->aux_stream[k]) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
+    // With several passes in flight every pipe runs on a stream of the scene's own, placed on hardware queues of their own
+    // (ensure_pipe_streams): with pipe 0 on the caller's stream, whatever other streams the host had made decided whether
+    // two pipes shared a queue.
+    if ((rc = ensure_pipe_streams(sc, n_pipes))) return rc;
 
     PassParams pp0;
     pp0.cam = *cam;
@@ -453,11 +526,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     } pipes[MAX_PIPES];
     for (int k = 0; k < n_pipes; ++k) {
         pipes[k].w = &sc->ws[k];
-        pipes[k].s = k ? sc->aux_stream[k] : stream;
+        pipes[k].s = n_pipes > 1 ? sc->aux_stream[k] : stream;
     }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
-        for (int k = 1; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
+        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
     }
     for (int k = 0; k < n_pipes; ++k) {
         // queue counters start at zero (every pass leaves them cleared again: k_accumulate), statistics too
@@ -696,11 +769,11 @@ int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts
     } pipes[MAX_PIPES];
     for (int k = 0; k < n_pipes; ++k) {
         pipes[k].w = &sc->ws[k];
-        pipes[k].s = k ? sc->aux_stream[k] : stream;
+        pipes[k].s = n_pipes > 1 ? sc->aux_stream[k] : stream;
     }
     if (n_pipes > 1) {
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
-        for (int k = 1; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
+        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
     }
     for (int k = 0; k < n_pipes; ++k) {
         HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
@@ -1195,6 +1268,8 @@ void rt_scene_destroy(rt_scene* sc) {
     DeviceGuard dg;
     if (hipSetDevice(sc->device) == hipSuccess) {
         for (auto& w : sc->ws) free_workspace(w);
+        for (auto& a : sc->pad_stream)
+            if (a) (void)hipStreamDestroy(a);
         for (auto& a : sc->aux_stream)
             if (a) (void)hipStreamDestroy(a);
         if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);

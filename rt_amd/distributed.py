@@ -43,19 +43,32 @@ def hip_resolve(out_sum, total_spp, device):
     return mean
 
 
-def render_distributed(render_sum, out_sum, spp_per_rank, seed=0, resolve=None):
+def render_distributed(render_sum, out_sum, spp_per_rank, seed=0, resolve=None, side_stream=None):
     """Every rank calls this.  render_sum(spp, offset, stride, seed, out_sum) must ADD the rank's
     per-pixel sums into out_sum (a float64 tensor, zeroed here).  Returns (mean or None, stats):
     the mean image only on rank 0.  resolve(out_sum, total_spp) -> mean: the division on rank 0 (default: a torch
-    division; GPU hosts pass hip_resolve so that the library's own resolve kernel runs)."""
+    division; GPU hosts pass hip_resolve so that the library's own resolve kernel runs).
+
+    side_stream (GPU hosts rendering frame after frame): the exchange step — the sum-reduce and rank 0's resolve — is
+    queued on that stream behind the render, so the next frame's kernels need not wait for the collective.  The caller
+    then owns the ordering: out_sum and the returned mean belong to side_stream until the caller has synchronised with
+    it (an event recorded on it, or a device synchronise), so consecutive frames alternate between two sum buffers."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     out_sum.zero_()
     spp, off, stride = partition(spp_per_rank, rank, world)
     stats = render_sum(spp, off, stride, seed, out_sum)
-    if dist.is_initialized():
-        dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
-    mean = None
-    if rank == 0:
-        mean = resolve(out_sum, spp_per_rank * world) if resolve else out_sum / float(spp_per_rank * world)
+
+    def exchange():
+        if dist.is_initialized():
+            dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
+        if rank != 0:
+            return None
+        return resolve(out_sum, spp_per_rank * world) if resolve else out_sum / float(spp_per_rank * world)
+
+    if side_stream is None:
+        return exchange(), stats
+    side_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side_stream):
+        mean = exchange()
     return mean, stats
