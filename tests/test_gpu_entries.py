@@ -108,3 +108,32 @@ def test_render_multi_one_device_equals_rt_render(mixed):
     assert L.rt_render_multi(handles, 2, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID
     assert b"same device" in L.rt_last_error()
     assert L.rt_render_multi(handles, 0, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID
+
+
+def test_streams_the_host_made_before_do_not_change_the_image(monkeypatch):
+    """A render with several passes in flight puts its pipes on streams of the scene's own and checks once per scene that
+    they sit on different hardware queues (ensure_pipe_streams); how many streams the host made before decides how many
+    idle streams that check parks.  None of it may show in the image."""
+    desc = scenes.mixed_test_scene(seed=5, n_spheres=30, quads=10)
+    cam = scenes.cover_camera(160, 90, spp=8, max_depth=20, defocus=True)
+    kw = dict(spp=8, seed=9, max_paths_in_flight=160 * 90 * 2, with_stats=True)      # four passes
+    base, st0 = cam.render_image(World.build(desc), **kw)
+    assert int(st0["passes"]) == 4
+    try:
+        hip = C.CDLL("libamdhip64.so")
+    except OSError:
+        hip = None
+    made = []
+    for extra in (1, 2):
+        if hip is not None:
+            for _ in range(extra):
+                s = C.c_void_p()
+                assert hip.hipStreamCreate(C.byref(s)) == 0
+                made.append(s)
+        img, st = cam.render_image(World.build(desc), **kw)
+        assert np.array_equal(img, base) and int(st["ray_segments"]) == int(st0["ray_segments"]), extra
+    monkeypatch.setenv("RT_HIP_STREAM_PROBE", "0")
+    img, _ = cam.render_image(World.build(desc), **kw)
+    assert np.array_equal(img, base)
+    for s in made:
+        hip.hipStreamDestroy(s)
