@@ -219,8 +219,8 @@ int rt_render(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
  * (width*height*3 doubles, added to what is there) on `stream` (a hipStream_t, NULL = default)
  * — the multi-GPU entry: ranks render disjoint sample indices, sum-reduce the buffers over RCCL,
  * then call rt_resolve_device once. (Extends the `.sum::<Vec3>()` of src/camera.rs:323.)
- * The call orders its work after what is already queued on `stream`, runs up to four passes on
- * streams of its own next to it, and returns when all of it has finished (the host sleeps in
+ * The call orders its work after what is already queued on `stream`, runs up to four passes at a
+ * time on streams of the scene's own (placed on different hardware queues, whatever streams the host has made), and returns when all of it has finished (the host sleeps in
  * hipStreamSynchronize meanwhile: every launch of the frame is queued up front), so the buffer is complete for any stream on return.  Calls on one
  * scene, and on one device, are serialised inside the library: the scene owns the path workspaces. */
 int rt_render_accumulate_device(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
