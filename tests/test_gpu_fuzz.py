@@ -85,3 +85,33 @@ def test_random_larger_scenes_match_oracle(oracle, case):
         np.testing.assert_allclose(img, want, rtol=RTOL, atol=ATOL, err_msg=str(c))
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_textured_meshes_match_oracle(oracle, case):
+    """The sweep over the image-textured mesh path (BASELINE config 4 in small: terrain + instanced icospheres, Metal with
+    image textures and fuzz on triangles, frosted dielectrics): random mesh sizes, texture sizes and cameras."""
+    g = np.random.default_rng(9000 + case)
+    desc = scenes.textured_scene(terrain_quads=int(g.integers(8, 41)), instances=int(g.integers(5, 121)), subdiv=int(g.integers(0, 3)),
+                                 n_textures=int(g.integers(1, 6)), tex_size=int(g.choice([8, 32, 100])), seed=int(g.integers(1, 1000)))
+    world, orc = World.build(desc), oracle.OracleScene(desc)
+    try:
+        n = 3000
+        o = g.uniform(-45.0, 45.0, (n, 3))
+        o[:, 2] = g.uniform(0.0, 15.0, n)
+        d = g.uniform(-1.0, 1.0, (n, 3))
+        d[:, 2] -= 0.5
+        rays = np.concatenate([o, d], -1)
+        gpu, ref = world.hit(rays), orc.hit(rays, mode=oracle.BVH_PRUNE)
+        bad = np.flatnonzero((gpu["prim"] != ref["prim"]) | (gpu["t"] != ref["t"]))
+        assert bad.size == 0, f"case {case}: {bad.size} closest hits differ"
+        ang = g.uniform(0, 2 * np.pi)
+        cam = Camera.new((float(60 * np.cos(ang)), float(60 * np.sin(ang)), float(g.uniform(8.0, 40.0))), (0.0, 0.0, 2.0), (0.0, 0.0, 1.0),
+                         10.0, 0.0, int(g.integers(40, 97)), int(g.integers(24, 65)), 2, int(g.choice([3, 12, 50])), float(g.uniform(25.0, 60.0)))
+        seed = int(g.integers(0, 2**31))
+        img, st = cam.render_image(world, spp=2, seed=seed, with_stats=True)
+        want, rst = orc.render(cam, 2, seed=seed, mode=oracle.BVH_PRUNE, with_stats=True)
+        assert int(st["ray_segments"]) == int(rst["ray_segments"]), case
+        np.testing.assert_allclose(img, want, rtol=RTOL, atol=ATOL)
+    finally:
+        orc.close()
