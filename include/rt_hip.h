@@ -123,8 +123,11 @@ typedef struct rt_opts {
     int32_t device;          /* HIP device ordinal                                            */
     uint32_t max_paths_in_flight; /* 0 = library default (2^26: 204 B of device memory each, for four passes in flight); paths per pass */
     uint32_t collect_stats;  /* 1: count nodes_visited / prims_tested (slower kernels)        */
-    uint32_t _pad;
+    uint32_t flags;          /* RT_OPT_* bits (0 = defaults; was padding before: old callers pass 0) */
 } rt_opts;
+/* rt_render_multi only: exchange the per-device sums as f32 (half the xGMI bytes: 24.9 MB per device at 1080p, 99.5 MB
+ * at 4K); every device still accumulates its own samples in f64, only the cross-device addition is f32. */
+#define RT_OPT_REDUCE_F32 1u
 
 typedef struct rt_stats {
     uint64_t samples;        /* camera paths traced                                     */
@@ -233,8 +236,9 @@ int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_valu
  * scenes[g] is the SAME scene created on device g's GPU (rt_scene_create once per device; n_devices distinct devices).
  * One host thread per device renders the frame's samples g, g + N, g + 2N, ... of opts->spp (opts->sample_offset /
  * sample_stride are applied first; opts->device is ignored) into a device buffer of per-pixel sums; the buffers are
- * summed into scenes[0]'s device with ncclReduce (f64, W*H*3 values; librccl.so.1 is loaded on first use), divided by
- * opts->spp there and copied to out_rgb_mean.  The union of the samples is that of rt_render with the same opts, so
+ * summed into scenes[0]'s device with ncclReduce (W*H*3 values, f64, or f32 with RT_OPT_REDUCE_F32; librccl.so.1 is
+ * loaded on first use), divided by opts->spp there and copied to out_rgb_mean.  The sum buffers and the stream of the
+ * exchange belong to the scenes (made on first use): no allocation per call after the first.  The union of the samples is that of rt_render with the same opts, so
  * the image differs only by the order of the cross-device additions (bit-identical for n_devices == 1).
  * stats: NULL or n_devices entries, one per device.  Extends `.sum::<Vec3>()` of src/camera.rs:316-324 across GPUs. */
 int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,

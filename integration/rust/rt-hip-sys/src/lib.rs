@@ -53,7 +53,9 @@ pub struct RtCamera { pub center: [f64; 3], pub pixel00: [f64; 3], pub pixel_du:
                       pub width: u32, pub height: u32, pub max_depth: u32, pub _pad: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct RtOpts { pub spp: u32, pub sample_offset: u32, pub sample_stride: u32, pub precision: u32, pub seed: u64,
-                    pub device: i32, pub max_paths_in_flight: u32, pub collect_stats: u32, pub _pad: u32 }
+                    pub device: i32, pub max_paths_in_flight: u32, pub collect_stats: u32, pub flags: u32 }
+/// `RtOpts::flags`: rt_render_multi exchanges the per-device sums as f32 (RT_OPT_REDUCE_F32)
+pub const RT_OPT_REDUCE_F32: u32 = 1;
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct RtStats {
     pub samples: u64, pub ray_segments: u64, pub nodes_visited: u64, pub prims_tested: u64,

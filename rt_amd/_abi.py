@@ -33,7 +33,8 @@ camera_dt = np.dtype([("center", "<f8", 3), ("pixel00", "<f8", 3), ("pixel_du", 
                       ("width", "<u4"), ("height", "<u4"), ("max_depth", "<u4"), ("_pad", "<u4")])
 opts_dt = np.dtype([("spp", "<u4"), ("sample_offset", "<u4"), ("sample_stride", "<u4"),
                     ("precision", "<u4"), ("seed", "<u8"), ("device", "<i4"),
-                    ("max_paths_in_flight", "<u4"), ("collect_stats", "<u4"), ("_pad", "<u4")])
+                    ("max_paths_in_flight", "<u4"), ("collect_stats", "<u4"), ("flags", "<u4")])
+OPT_REDUCE_F32 = 1
 stats_dt = np.dtype([("samples", "<u8"), ("ray_segments", "<u8"), ("nodes_visited", "<u8"),
                      ("prims_tested", "<u8"), ("passes", "<u4"), ("launches", "<u4"),
                      ("seconds_trace", "<f8"), ("seconds_shade", "<f8"), ("seconds_total", "<f8"),

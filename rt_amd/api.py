@@ -431,8 +431,9 @@ class Camera:
     max_depth = property(lambda self: int(self.rec["max_depth"][0]))
 
     def opts(self, spp=None, sample_offset=0, sample_stride=1, seed=0, device=0, max_paths_in_flight=0,
-             collect_stats=False):
+             collect_stats=False, reduce_f32=False):
         o = _abi.one(_abi.opts_dt)
+        o["flags"] = _abi.OPT_REDUCE_F32 if reduce_f32 else 0      # rt_render_multi only: f32 exchange of the per-device sums
         o["spp"] = self.samples_per_pixel if spp is None else spp
         o["sample_offset"], o["sample_stride"] = sample_offset, sample_stride
         o["precision"], o["seed"], o["device"] = 64, seed, device

@@ -6,9 +6,11 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <limits>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 namespace rt {
@@ -67,7 +69,11 @@ struct Task {
 class Team {
 public:
     explicit Team(unsigned threads) {
-        for (unsigned i = 1; i < threads; ++i) workers.emplace_back([this] { loop(); });
+        // a thread that cannot be started is not an error: the team is then smaller (down to the caller alone)
+        try {
+            for (unsigned i = 1; i < threads; ++i) workers.emplace_back([this] { loop(); });
+        } catch (const std::system_error&) {
+        }
     }
     ~Team() {
         {
@@ -81,7 +87,7 @@ public:
     unsigned size() const { return (unsigned)workers.size() + 1u; }
     void run(size_t n, const std::function<void(size_t)>& fn) {
         if (workers.empty() || n <= 1) {
-            for (size_t k = 0; k < n; ++k) fn(k);
+            for (size_t k = 0; k < n; ++k) fn(k);      // (on the caller: exceptions propagate as they are)
             return;
         }
         {
@@ -94,9 +100,17 @@ public:
         }
         cv_job.notify_all();
         drain(fn, n);
-        std::unique_lock<std::mutex> l(m);
-        cv_done.wait(l, [&] { return busy == 0; });
-        job = nullptr;
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv_done.wait(l, [&] { return busy == 0; });
+            job = nullptr;
+            err = failure;
+            failure = nullptr;
+        }
+        // an exception inside fn (bad_alloc from a vector, say) on whichever thread is raised again HERE, on the caller:
+        // a worker thread has no handler, and the entry points of the library catch on their own thread
+        if (err) std::rethrow_exception(err);
     }
 
 private:
@@ -104,7 +118,13 @@ private:
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= n) return;
-            fn(k);
+            try {
+                fn(k);
+            } catch (...) {
+                std::lock_guard<std::mutex> l(m);
+                if (!failure) failure = std::current_exception();
+                next.store(n);             // nobody starts another piece
+            }
         }
     }
     void loop() {
@@ -135,6 +155,7 @@ private:
     std::atomic<size_t> next{0};
     unsigned long long generation = 0;
     bool stop = false;
+    std::exception_ptr failure;        // first exception of the run in flight (under m)
 };
 
 // [0, n) in pieces of `piece` elements: piece k is [k*piece, min(n, (k+1)*piece))

@@ -83,6 +83,57 @@ int select_device(int device) {
 
 constexpr int MAX_PIPES = 8;
 
+// ---- debug / test switches ------------------------------------------------------------------------------------------
+// The environment is read in ONE place, into this struct: when a scene is created (builder, node format, walk mode) and
+// again at the start of every entry point that traces or renders — once per call, never per pass or per launch — so that
+// a test can flip a switch between two calls on the same scene.  None of them changes a result; the tests that compare
+// the variants bit for bit are named beside each switch.
+struct Tuning {
+    // scene creation
+    std::string builder;          // RT_HIP_BUILDER=lbvh: the device builder (tests/test_gpu_parity.py: both builders, same hits)
+    std::string node_boxes;       // RT_HIP_NODE_BOXES=f64|f32|q16|w4|w4f|w8: force a node format (test_gpu_parity.py: every format)
+    int all_lanes_load = -1;      // RT_HIP_ALL_LANES_LOAD=0|1: every-lane-fetches walk off / on (default: by scene size)
+    // per call
+    bool no_packet = false;       // RT_HIP_NO_PACKET: camera rays through the per-lane walk (test_gpu_configs.py: kernel variants)
+    bool no_fuse = false;         // RT_HIP_NO_FUSE: depth-0 shading in k_shade instead of the camera-ray kernel
+    bool primary_packet = false;  // RT_HIP_PRIMARY_PACKET: rt_trace_primary through the coherent-wave kernel
+    bool debug = false;           // RT_HIP_DEBUG_UTIL: diagnostics on stderr
+    bool stream_probe = true;     // RT_HIP_STREAM_PROBE=0: do not check that the pipes' streams sit on queues of their own
+    int pipes = 0;                // RT_HIP_PIPES=<1..8>: passes in flight (default 4)
+    int tail_depth = 0;           // RT_HIP_TAIL_DEPTH=<d>: depth from which the persistent kernel takes over (default: adaptive)
+    int stagger = 1;              // RT_HIP_STAGGER=0|1|2
+    int group = 0;                // RT_HIP_GROUP=1|4|16|64: cap of the samples of a pixel that share a wave
+    int paths_log2 = 0;           // RT_HIP_PATHS_IN_FLIGHT=<log2>: default cap of the paths of a pass
+    int hw_queues = 4;            // GPU_MAX_HW_QUEUES (HIP's own variable; 4 is its default)
+    bool no_refill = false;       // RT_HIP_NO_REFILL=1: one chunk per wave instead of persistent walk launches
+    int refill_slots = 0;         // RT_HIP_REFILL_SLOTS=<n>: number of persistent waves
+    int ovf_lds_rows = 0;         // RT_HIP_OVF_LDS_ROWS=<4..32>: LDS rows of the overflow-stack walk
+};
+Tuning read_tuning() {
+    auto str = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e && *e ? atoi(e) : dflt; };
+    auto set = [](const char* n) { return getenv(n) != nullptr; };
+    Tuning t;
+    t.builder = str("RT_HIP_BUILDER");
+    t.node_boxes = str("RT_HIP_NODE_BOXES");
+    t.all_lanes_load = set("RT_HIP_ALL_LANES_LOAD") ? (num("RT_HIP_ALL_LANES_LOAD", 0) != 0 ? 1 : 0) : -1;
+    t.no_packet = set("RT_HIP_NO_PACKET");
+    t.no_fuse = set("RT_HIP_NO_FUSE");
+    t.primary_packet = set("RT_HIP_PRIMARY_PACKET");
+    t.debug = set("RT_HIP_DEBUG_UTIL");
+    t.stream_probe = num("RT_HIP_STREAM_PROBE", 1) != 0;
+    t.pipes = num("RT_HIP_PIPES", 0);
+    t.tail_depth = num("RT_HIP_TAIL_DEPTH", 0);
+    t.stagger = num("RT_HIP_STAGGER", 1);
+    t.group = num("RT_HIP_GROUP", 0);
+    t.paths_log2 = num("RT_HIP_PATHS_IN_FLIGHT", 0);
+    t.hw_queues = std::max(1, num("GPU_MAX_HW_QUEUES", 4));
+    t.no_refill = num("RT_HIP_NO_REFILL", 0) == 1;
+    t.refill_slots = std::max(0, num("RT_HIP_REFILL_SLOTS", 0));
+    t.ovf_lds_rows = num("RT_HIP_OVF_LDS_ROWS", 0);
+    return t;
+}
+
 // ---- scratch of rt_trace_closest_noalloc (include/rt_hip.h) -------------------------------------
 // The ray queue (o, d: 6 doubles + path id) and the hit buffer (t, bu, bv + primitive id) of one bounded batch live
 // in a file-scope device array instead of a hipMalloc'ed workspace: 80 B per queue slot, RT_NOALLOC_MAX_RAYS rays +
@@ -155,9 +206,26 @@ struct rt_scene {
     double alive_ratio[HIST_DEPTHS] = {};
     // depth from which the persistent trace-and-shade kernel takes over; follows the reported queue sizes (render_into)
     uint32_t tail_depth = 4;
+    // rt_render_multi: this device's radiance sums (f64), their f32 copy for RT_OPT_REDUCE_F32, and the stream the render
+    // and the reduce are queued on — grow-only, made on first use, freed with the scene (no hipMalloc / stream per call)
+    double* mg_sum = nullptr;
+    float* mg_sum32 = nullptr;
+    size_t mg_cap = 0, mg_cap32 = 0;       // in values
+    hipStream_t mg_stream = nullptr;
+    Tuning tune;                     // the switches as the running call read them (refresh_tuning)
+    LaunchCtx lctx;                  // what the walk launchers keep for this scene's device
 };
 
 namespace {
+
+// start of every tracing / rendering entry point, with the device's mutex held
+void refresh_tuning(rt_scene* sc) {
+    sc->tune = read_tuning();
+    sc->lctx.refill = !sc->tune.no_refill;
+    sc->lctx.refill_slots = (unsigned)sc->tune.refill_slots;
+    const int r = sc->tune.ovf_lds_rows;
+    sc->lctx.ovf_lds_rows = r >= 4 && r <= (int)OVF_LDS_ROWS ? (uint32_t)r : OVF_LDS_ROWS;
+}
 
 void free_workspace(Workspace& w) {
     if (w.base) (void)hipFree(w.base);
@@ -189,7 +257,7 @@ int ensure_workspace(rt_scene* sc, size_t paths, int which = 0) {
     }
     // deep trees: the rows of the traversal stack beyond its LDS part, a column per lane of a persistent launch
     // (16 waves per CU is what the registers of the traversal kernel allow at most)
-    const uint32_t ovf_rows = stack_overflow_rows(sc->d);
+    const uint32_t ovf_rows = stack_overflow_rows(sc->d, sc->lctx.ovf_lds_rows);
     if (ovf_rows > w.ovf.rows_cap) {
         if (w.ovf.rows) (void)hipFree(w.ovf.rows);
         w.ovf = {nullptr, 0u, 0u};
@@ -314,11 +382,6 @@ constexpr size_t DEFAULT_PATHS_IN_FLIGHT = size_t(1) << 26;
 constexpr int DEFAULT_PIPES = 4;
 constexpr size_t PRIMARY_MAX_PIXELS = size_t(1) << 25;
 
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-
 // ---- streams of the passes in flight ---------------------------------------------------------------------------------
 // A HIP process has GPU_MAX_HW_QUEUES hardware queues (4 here) and every stream is put on the one that carries the fewest
 // streams at that moment: four streams made in a row sit on four different queues only if the streams the host made
@@ -361,22 +424,33 @@ int pipes_side_by_side(rt_scene* sc, int n, bool* ok) {
     (void)hipEventDestroy(start);
     for (int k = 0; k < n; ++k) (void)hipEventDestroy(end[k]);
     *ok = worst < 1.6f * (float)PROBE_US * 1e-3f;
-    if (getenv("RT_HIP_DEBUG_UTIL")) fprintf(stderr, "[rt_hip] %d pipe streams: probe waves done after %.0f us (%s)\n", n, worst * 1e3f, *ok ? "side by side" : "queued behind each other");
+    if (sc->tune.debug) fprintf(stderr, "[rt_hip] %d pipe streams: probe waves done after %.0f us (%s)\n", n, worst * 1e3f, *ok ? "side by side" : "queued behind each other");
     return RT_OK;
 }
 
 int ensure_pipe_streams(rt_scene* sc, int n_pipes) {
     if (n_pipes <= 1 || sc->n_aux >= n_pipes) return RT_OK;
-    auto drop = [&]() {
-        for (int k = 0; k < sc->n_aux; ++k)
+    auto drop = [&]() {                              // every slot, so that a partly failed creation loop is cleaned up too
+        for (int k = 0; k < MAX_PIPES; ++k)
             if (sc->aux_stream[k]) { (void)hipStreamDestroy(sc->aux_stream[k]); sc->aux_stream[k] = nullptr; }
         sc->n_aux = 0;
     };
     drop();                                          // (no pass is in flight here: the caller holds the scene)
-    const int hw_queues = std::max(1, env_int("GPU_MAX_HW_QUEUES", 4));
-    const bool probe = n_pipes <= hw_queues && env_int("RT_HIP_STREAM_PROBE", 1) != 0;
+    // a render that needs more pipes than the one before starts the placement over: the idle streams parked for the old
+    // set go too, so that their number is again what the probe below finds necessary
+    for (auto& ps : sc->pad_stream)
+        if (ps) { (void)hipStreamDestroy(ps); ps = nullptr; }
+    const bool probe = n_pipes <= sc->tune.hw_queues && sc->tune.stream_probe;
     for (int attempt = 0;; ++attempt) {
-        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking));
+        for (int k = 0; k < n_pipes; ++k) {
+            hipError_t e = hipStreamCreateWithFlags(&sc->aux_stream[k], hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                sc->aux_stream[k] = nullptr;
+                drop();
+                return fail(RT_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorName(e));
+            }
+        }
         sc->n_aux = n_pipes;
         if (!probe || attempt == 3) return RT_OK;
         bool ok = false;
@@ -387,9 +461,6 @@ int ensure_pipe_streams(rt_scene* sc, int n_pipes) {
         HIPCHK(hipStreamCreateWithFlags(&sc->pad_stream[attempt], hipStreamNonBlocking));
     }
 }
-
-int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
-                         rt_stats* stats, uint32_t per_pass, uint32_t n_passes, int n_pipes, const PassParams& pp0, uint32_t group_cap);
 
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
 //
@@ -414,14 +485,15 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         return fail(RT_ERR_LIMIT, "sample index %llu exceeds the Halton table limit %u (src/camera.rs:208-210)",
                     (unsigned long long)last, RT_MAX_SAMPLE_INDEX);
     const size_t npix = (size_t)cam->width * cam->height;
-    const int pfe = env_int("RT_HIP_PATHS_IN_FLIGHT", 0);          // experiments: log2 of the default cap
+    const Tuning& tune = sc->tune;
+    const int pfe = tune.paths_log2;                               // experiments: log2 of the default cap
     const size_t dflt = pfe >= 10 && pfe <= 30 ? size_t(1) << pfe : DEFAULT_PATHS_IN_FLIGHT;
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
     uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
     // Several passes are kept in flight, one stream each: the tail of a pass (few paths, long dependent chains) hides
     // behind the other passes' bulk work.  RT_HIP_PIPES=<n> sets the number (1 disables the overlap).
-    const int pe = env_int("RT_HIP_PIPES", 0);
+    const int pe = tune.pipes;
     const uint32_t want_pipes = pe >= 1 ? (uint32_t)std::min(pe, MAX_PIPES) : (uint32_t)DEFAULT_PIPES;
     uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
     int n_pipes = (int)std::min<uint32_t>(n_passes, want_pipes);
@@ -493,17 +565,14 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     pp0.jitter_table = nullptr;
     // samples of a pixel that share a wave of camera rays: as many as the pass and the frame allow
     // (RT_HIP_GROUP=1|4|16|64 caps it; 1 = one sample of an 8x8 tile per wave)
-    const int ge = env_int("RT_HIP_GROUP", 0);
+    const int ge = tune.group;
     const uint32_t group_cap = ge > 0 ? (uint32_t)ge : 16u;
-
-    if (env_int("RT_HIP_HOST_LOOP", 0) && !opts->collect_stats)
-        return render_into_hostloop(sc, cam, opts, d_rgb_sum, stream, stats, per_pass, n_passes, n_pipes, pp0, group_cap);
 
     rt_stats st;
     memset(&st, 0, sizeof(st));
     const bool want_stats = opts->collect_stats != 0;
-    const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
-    const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");      // depth-0 shading inside the camera-ray kernel
+    const bool use_packet = !tune.no_packet && packet_supported(sc->d);
+    const bool fuse_shade = use_packet && !tune.no_fuse;      // depth-0 shading inside the camera-ray kernel
     // Depth from which the persistent trace-and-shade kernel takes over.  Stand-alone k_walk + k_shade launches are the
     // efficient way through a queue of any size (full occupancy, half the registers), the persistent kernel is the way
     // through the few thousand paths that are left after some bounces (one launch, no matter how deep they go): the
@@ -511,10 +580,10 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     // read from the reported sizes where a stand-alone pair ran, extrapolated with the last decay ratio beyond them (the
     // persistent kernel reports only the size it starts with) — and comes back one depth when the last stand-alone pair
     // saw fewer than a quarter of that.  RT_HIP_TAIL_DEPTH=<d> fixes it (tests, A/B).  The image does not depend on it.
-    const uint32_t TAIL_MAX_PATHS = (uint32_t)std::max(1, env_int("RT_HIP_TAIL_MAX_PATHS", 1 << 15));
-    const int td_env = env_int("RT_HIP_TAIL_DEPTH", 0);
+    constexpr uint32_t TAIL_MAX_PATHS = 1u << 15;
+    const int td_env = tune.tail_depth;
     auto tail_depth_now = [&]() -> uint32_t { return td_env > 0 ? (uint32_t)td_env : sc->tail_depth; };
-    const int stagger_mode = env_int("RT_HIP_STAGGER", 1);
+    const int stagger_mode = tune.stagger;
     const bool stagger = stagger_mode != 0;
 
     struct Pipe {
@@ -576,15 +645,16 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         return RT_OK;
     };
     auto estimate = [&](uint32_t depth, uint32_t n) -> uint32_t {
-        if (depth >= (uint32_t)HIST_DEPTHS || !(sc->alive_ratio[depth] > 0.0) || getenv("RT_HIP_NO_ESTIMATE")) return 0u;
+        if (depth >= (uint32_t)HIST_DEPTHS || !(sc->alive_ratio[depth] > 0.0)) return 0u;
         return (uint32_t)std::min<double>((double)n, sc->alive_ratio[depth] * (double)n + 1.0);
     };
 
     int prev_pipe = -1;
-    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+    // queues one pass on its pipe; a failure in here leaves the other pipes' work in flight: the caller drains them all
+    auto queue_pass = [&](uint32_t pass) -> int {
         const int k = (int)(pass % (uint32_t)n_pipes);
         Pipe& P = pipes[k];
-        if ((rc = collect(P))) return rc;            // (also: the pipe's events are free to be recorded again)
+        if (int crc = collect(P)) return crc;        // (also: the pipe's events are free to be recorded again)
         Workspace& w = *P.w;
         const uint32_t base = pass * per_pass;
         const uint32_t nl = std::min(per_pass, opts->spp - base);
@@ -593,7 +663,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         pp.pass_base = base;
         for (uint32_t g = 64; g > 1; g >>= 2)
             if (g <= group_cap && nl % g == 0 && npix % (64u / g) == 0) { pp.group = g; break; }
-        if (w.jitter_cap >= nl && !getenv("RT_HIP_NO_JITTER_TABLE")) {
+        if (w.jitter_cap >= nl) {
             pp.jitter_table = w.jitter;
             launch_jitter_table(pp, nl, w.jitter, P.s);
             st.launches++;
@@ -620,7 +690,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.launches++;
         } else {
             launch_raygen(pp, dense, w.q[0], P.s);
-            launch_walk(sc->d, w.q[0], dense, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s, 0, &w.ovf);
+            launch_walk(sc->lctx, sc->d, w.q[0], dense, n, cam->t_min, cam->t_max, w.hb, want_stats, sg_primary, P.s, 0, &w.ovf);
             st.launches += 2;
         }
         if (!fuse_shade) {
@@ -638,7 +708,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const uint32_t tail_depth = tail_depth_now();
         for (; depth < tail_depth && depth <= cam->max_depth; ++depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk(sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, depth == 1 ? sg_bounce : sg_deep, ws, estimate(depth, n), &w.ovf);
+            launch_walk(sc->lctx, sc->d, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, want_stats, depth == 1 ? sg_bounce : sg_deep, ws, estimate(depth, n), &w.ovf);
             st.trace_launches++;
             if (depth == 1) st.bounce_launches++;
             if (!ev2) { HIPCHK(hipEventRecord(w.ev[2], ws)); ev2 = true; }
@@ -656,7 +726,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         // ---- every remaining bounce inside one persistent launch
         if (depth <= cam->max_depth) {
             const QueueGeom qg = {cnt[cset], scap, 0u};
-            launch_walk_shade(sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance,
+            launch_walk_shade(sc->lctx, sc->d, pp, depth, w.q[cur], qg, n, cam->t_min, cam->t_max, w.hb, w.path_radiance,
                               depth < (uint32_t)HIST_DEPTHS ? w.hist + depth : nullptr, want_stats, sg_tail, ws, estimate(depth, n), &w.ovf);
             st.launches++;
         }
@@ -676,22 +746,35 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         P.n = n;
         P.tail_depth = tail_depth;
         prev_pipe = k;
-    }
+        return RT_OK;
+    };
+    int loop_rc = RT_OK;
+    std::string loop_err;
+    for (uint32_t pass = 0; pass < n_passes && !loop_rc; ++pass)
+        if ((loop_rc = queue_pass(pass))) loop_err = g_err;
+    // Drain EVERY pipe before returning, whatever happened while queueing or on another pipe: the kernels in flight read
+    // and write the scene's workspaces and the caller's sum buffer, and the next call on this scene reuses both.
     int first_err = RT_OK;
-    for (int k = 0; k < n_pipes; ++k) {      // drain every pipe, whatever happened on another one
-        hipError_t e = hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s);
+    for (int k = 0; k < n_pipes; ++k) {
+        hipError_t e = loop_rc ? hipSuccess
+                               : hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s);
         if (e == hipSuccess) e = hipStreamSynchronize(pipes[k].s);
         if (e != hipSuccess && !first_err) {
             (void)hipGetLastError();
             first_err = fail(RT_ERR_HIP, "render: %s on pipe %d", hipGetErrorName(e), k);
         }
     }
+    if (loop_rc) {                           // the first failure is the one reported
+        (void)hipGetLastError();
+        g_err = loop_err;
+        return loop_rc;
+    }
     if (first_err) return first_err;
     for (int k = 0; k < n_pipes; ++k)
         if ((rc = collect(pipes[k]))) return rc;
     HIPCHK(hipGetLastError());
     st.seconds_total = now_s() - t0;
-    if (getenv("RT_HIP_DEBUG_UTIL")) {
+    if (tune.debug) {
         fprintf(stderr, "[rt_hip] tail depth %u; queue sizes by depth (last pass of pipe 0):", sc->tail_depth);
         for (int d = 1; d < HIST_DEPTHS && pipes[0].w->h_hist[d]; ++d) fprintf(stderr, " %u", pipes[0].w->h_hist[d]);
         fprintf(stderr, "\n");
@@ -703,13 +786,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
         const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
         const unsigned long long* hd = h + STAT_GROUP * STAT_GROUP_DEEP;
-#ifdef RT_TIMING
-        if (getenv("RT_HIP_DEBUG_UTIL") && hp[12])
-            fprintf(stderr, "[rt_hip] pipe %d camera-ray wave (every 64th), cycles in flight: generation %.0f, %.1f node steps %.0f (%.1f each), "
-                    "%.1f primitive steps %.0f (%.1f each), shading + append %.0f\n", k, (double)hp[8] / hp[12], (double)hp[13] / hp[12],
-                    (double)hp[9] / hp[12], (double)hp[9] / std::max(1.0, (double)hp[13]), (double)hp[14] / hp[12], (double)hp[10] / hp[12],
-                    (double)hp[10] / std::max(1.0, (double)hp[14]), (double)hp[11] / hp[12]);
-#endif
         st.bounce_segments += hb_[STAT_SEGMENTS];
         st.tail_segments += ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
         st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
@@ -722,18 +798,12 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             st.prims_tested_bounce += hb_[STAT_PRIMS];
             st.wave_node_fetches_primary += hp[STAT_WAVE_NODES];
             st.wave_prim_fetches_primary += hp[STAT_WAVE_PRIMS];
-            if (getenv("RT_HIP_DEBUG_UTIL")) {      // bounce launches: lane steps / (64 x wave loop iterations)
+            if (tune.debug) {      // bounce launches: lane steps / (64 x wave loop iterations)
                 fprintf(stderr, "[rt_hip] pipe %d camera rays: %llu node records fetched per wave-launch, %llu of them dead ends "
                         "(no ray entered a child), %llu primitive records\n", k, hp[STAT_WAVE_NODES], hp[STAT_LEAVES], hp[STAT_WAVE_PRIMS]);
                 fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
                         k, hb_[STAT_NODES], hb_[STAT_LEAVES], hb_[STAT_ITERS],
                         hb_[STAT_ITERS] ? (double)(hb_[STAT_NODES] + hb_[STAT_LEAVES]) / (64.0 * (double)hb_[STAT_ITERS]) : 0.0);
-#ifdef RT_TIMING
-                const double it = (double)hb_[STAT_ITERS];
-                fprintf(stderr, "[rt_hip] pipe %d cycles per wave iteration: issue %.1f wait %.1f node %.1f prim %.1f refill %.1f; "
-                        "iterations with a node step %.3f, with a primitive step %.3f\n", k, hb_[8] / it, hb_[9] / it, hb_[10] / it, hb_[11] / it,
-                        hb_[12] / it, hb_[13] / it, hb_[14] / it);
-#endif
             }
         }
     }
@@ -741,165 +811,32 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     return RT_OK;
 }
 
-
-// EXPERIMENT / A-B (RT_HIP_HOST_LOOP=1): the round-1 schedule on the same kernels — the host reads the queue counts after every
-// bounce (pinned copy + event, polled), sizes every launch exactly and runs stand-alone k_walk + k_shade pairs until no
-// path is left.  One host round trip per bounce and pipe; kept to measure what the device-driven schedule gains or loses.
-int render_into_hostloop(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double* d_rgb_sum, hipStream_t stream,
-                         rt_stats* stats, uint32_t per_pass, uint32_t n_passes, int n_pipes, const PassParams& pp0, uint32_t group_cap) {
-    const size_t npix = (size_t)cam->width * cam->height;
-    rt_stats st;
-    memset(&st, 0, sizeof(st));
-    const bool use_packet = !getenv("RT_HIP_NO_PACKET") && packet_supported(sc->d);
-    const bool fuse_shade = use_packet && !getenv("RT_HIP_NO_FUSE");
-    static uint32_t* h_counts[MAX_PIPES] = {};
-    static hipEvent_t ev_b[MAX_PIPES] = {};
-    for (int k = 0; k < n_pipes; ++k)
-        if (!h_counts[k]) {
-            HIPCHK(hipHostMalloc((void**)&h_counts[k], COUNTER_BYTES, hipHostMallocDefault));
-            HIPCHK(hipEventCreateWithFlags(&ev_b[k], hipEventDisableTiming));
-        }
-    struct Pipe {
-        Workspace* w = nullptr;
-        hipStream_t s = nullptr;
-        PassParams pp;
-        uint32_t pass = 0, nl = 0, n = 0, depth = 0, scap = 0, n_waves = 0;
-        int cur = 0, cset = 0;
-        enum { IDLE, RUNNING, WAIT_ACC } state = IDLE;
-    } pipes[MAX_PIPES];
-    for (int k = 0; k < n_pipes; ++k) {
-        pipes[k].w = &sc->ws[k];
-        pipes[k].s = n_pipes > 1 ? sc->aux_stream[k] : stream;
-    }
-    if (n_pipes > 1) {
-        HIPCHK(hipEventRecord(sc->ev_fork, stream));
-        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
-    }
-    for (int k = 0; k < n_pipes; ++k) {
-        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
-        HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
-    }
-    uint32_t next_pass = 0, next_acc = 0, done_passes = 0;
-    int last_acc_pipe = -1, rc;
-    const double t0 = now_s();
-    auto cnt_of = [&](Pipe& P, int set) { return P.w->counters + (COUNTER_BYTES / 4) * set; };
-    auto readback = [&](Pipe& P, int k) -> int {      // counts of the queue the last shade produced
-        HIPCHK(hipMemcpyAsync(h_counts[k], cnt_of(P, P.cset), COUNTER_BYTES, hipMemcpyDeviceToHost, P.s));
-        HIPCHK(hipEventRecord(ev_b[k], P.s));
-        return RT_OK;
-    };
-    auto start_pass = [&](Pipe& P, int k) -> int {
-        Workspace& w = *P.w;
-        P.pass = next_pass++;
-        const uint32_t base = P.pass * per_pass;
-        P.nl = std::min(per_pass, opts->spp - base);
-        P.n = (uint32_t)(npix * P.nl);
-        P.pp = pp0;
-        P.pp.pass_base = base;
-        for (uint32_t g = 64; g > 1; g >>= 2)
-            if (g <= group_cap && P.nl % g == 0 && npix % (64u / g) == 0) { P.pp.group = g; break; }
-        finish_pass_params(P.pp);
-        P.scap = shard_cap_for(P.n);
-        const QueueGeom dense = {nullptr, P.scap, P.n};
-        HIPCHK(hipMemsetAsync(w.counters, 0, 2 * COUNTER_BYTES, P.s));
-        if (use_packet) {
-            PacketFuse f = {w.q[1], cnt_of(P, 0), w.path_radiance};
-            launch_trace_packet(sc->d, &P.pp, w.q[0], dense, cam->t_min, cam->t_max, w.hb, false, nullptr, P.s, fuse_shade ? &f : nullptr);
-        } else {
-            launch_raygen(P.pp, dense, w.q[0], P.s);
-            launch_walk(sc->d, w.q[0], dense, P.n, cam->t_min, cam->t_max, w.hb, false, nullptr, P.s);
-        }
-        if (!fuse_shade) launch_shade(sc->d, P.pp, 0u, w.q[0], dense, P.n, 0u, w.hb, w.q[1], cnt_of(P, 0), w.path_radiance, nullptr, P.s);
-        st.launches += 2;
-        st.primary_segments += P.n;
-        P.cur = 1; P.cset = 0; P.depth = 0;
-        P.state = Pipe::RUNNING;
-        return readback(P, k);
-    };
-    auto bounce = [&](Pipe& P, int k) -> int {       // queue q[cur] / counts cset, P.n entries in P.n_waves logical waves
-        Workspace& w = *P.w;
-        const QueueGeom qg = {cnt_of(P, P.cset), P.scap, 0u};
-        launch_walk(sc->d, w.q[P.cur], qg, P.n_waves * 64u, cam->t_min, cam->t_max, w.hb, false,
-                    w.stat_counters + STAT_GROUP * STAT_GROUP_BOUNCE, P.s);
-        HIPCHK(hipMemsetAsync(cnt_of(P, P.cset ^ 1), 0, COUNTER_BYTES, P.s));
-        launch_shade(sc->d, P.pp, P.depth, w.q[P.cur], qg, P.n, 0u, w.hb, w.q[P.cur ^ 1], cnt_of(P, P.cset ^ 1), w.path_radiance, nullptr,
-                     P.s, P.n_waves);
-        st.launches += 2;
-        st.trace_launches++;
-        P.cur ^= 1; P.cset ^= 1;
-        return readback(P, k);
-    };
-    auto accumulate = [&](Pipe& P, int k) -> int {
-        if (last_acc_pipe >= 0 && last_acc_pipe != k) HIPCHK(hipStreamWaitEvent(P.s, sc->ev_acc[last_acc_pipe], 0));
-        launch_accumulate(P.pp, P.w->path_radiance, P.nl, d_rgb_sum, nullptr, 0u, P.s);
-        HIPCHK(hipEventRecord(sc->ev_acc[k], P.s));
-        last_acc_pipe = k;
-        ++next_acc; ++done_passes;
-        st.launches++; st.passes++;
-        st.samples += (uint64_t)npix * P.nl;
-        P.state = Pipe::IDLE;
-        return RT_OK;
-    };
-    if ((rc = start_pass(pipes[0], 0))) return rc;
-    int started = 1;
-    while (done_passes < n_passes) {
-        bool progressed = false;
-        for (int k = 0; k < n_pipes; ++k) {
-            Pipe& P = pipes[k];
-            if (P.state == Pipe::IDLE) {
-                if (next_pass < n_passes && k < started) {
-                    if ((rc = start_pass(P, k))) return rc;
-                    progressed = true;
-                }
-                continue;
-            }
-            if (P.state == Pipe::WAIT_ACC) {
-                if (P.pass == next_acc) {
-                    if ((rc = accumulate(P, k))) return rc;
-                    progressed = true;
-                }
-                continue;
-            }
-            const hipError_t qe = hipEventQuery(ev_b[k]);
-            if (qe == hipErrorNotReady) continue;
-            if (qe != hipSuccess) HIPCHK(qe);
-            progressed = true;
-            uint32_t tot = 0, mx = 0;
-            for (int sh = 0; sh < NSHARD; ++sh) {
-                const uint32_t c = h_counts[k][COUNT_STRIDE * sh];
-                tot += c;
-                mx = std::max(mx, (c + 63u) / 64u);
-            }
-            P.n = tot;
-            P.n_waves = mx * NSHARD;
-            P.depth++;
-            if (k == started - 1 && started < n_pipes) {
-                ++started;
-                if (next_pass < n_passes && (rc = start_pass(pipes[started - 1], started - 1))) return rc;
-            }
-            if (P.n == 0 || P.depth > cam->max_depth) {
-                P.state = Pipe::WAIT_ACC;
-                if (P.pass == next_acc && (rc = accumulate(P, k))) return rc;
-            } else if ((rc = bounce(P, k))) {
-                return rc;
-            }
-        }
-        if (!progressed) std::this_thread::yield();
-    }
-    for (int k = 0; k < n_pipes; ++k) {
-        HIPCHK(hipMemcpyAsync(pipes[k].w->h_stat, pipes[k].w->stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, pipes[k].s));
-        HIPCHK(hipStreamSynchronize(pipes[k].s));
-    }
+// The body of rt_trace_closest_noalloc: with the scene's device current and its mutex held, queues the three launches
+// on `stream`.  Calls nothing that allocates once the scene's creation has warmed it up.
+int trace_noalloc_queued(rt_scene* sc, const rt_ray* d_rays, size_t n, double t_min, double t_max, rt_hit* d_hits, hipStream_t stream) {
+    int rc;
+    unsigned char* base = nullptr;                      // the device address kept at set-up (rt_scene_create)
+    if ((rc = noalloc_scratch_for(sc->device, &base))) return rc;
+    // carve the array: every kernel below gets these pointers as arguments, like the workspace of rt_trace_closest
+    double* dp = (double*)base;
+    uint32_t* up = (uint32_t*)(base + NOALLOC_DOUBLES * sizeof(double));
+    RayQueue q{};
+    HitBuf hb{};
+    for (int c = 0; c < 3; ++c) q.o[c] = dp + (size_t)c * NOALLOC_SLOTS;
+    for (int c = 0; c < 3; ++c) q.d[c] = dp + (size_t)(3 + c) * NOALLOC_SLOTS;
+    for (int c = 0; c < 3; ++c) q.thr[c] = nullptr;     // the traversal never touches the throughput
+    hb.t = dp + 6 * NOALLOC_SLOTS;
+    hb.bu = dp + 7 * NOALLOC_SLOTS;
+    hb.bv = dp + 8 * NOALLOC_SLOTS;
+    q.pid = up;
+    hb.prim = up + NOALLOC_SLOTS;
+    // Nothing has to start at zero: k_prepare_rays writes every queue slot the traversal reads, the traversal writes t and
+    // prim of every one of them (bu / bv are not read by k_pack_hits), and no counter is involved (stats are off).
+    const QueueGeom qg = {nullptr, shard_cap_for(n), (uint32_t)n};
+    launch_prepare_rays(d_rays, qg, q, stream);
+    launch_walk(sc->lctx, sc->d, q, qg, (uint32_t)n, t_min, t_max, hb, false, nullptr, stream);
+    launch_pack_hits(hb, qg, d_hits, stream);
     HIPCHK(hipGetLastError());
-    st.seconds_total = now_s() - t0;
-    st.ray_segments = st.primary_segments;
-    for (int k = 0; k < n_pipes; ++k) {
-        const unsigned long long* hb_ = pipes[k].w->h_stat + STAT_GROUP * STAT_GROUP_BOUNCE;
-        st.bounce_segments += hb_[STAT_SEGMENTS];
-        st.ray_segments += hb_[STAT_SEGMENTS];
-    }
-    st.seconds_trace_bounce = st.seconds_trace_primary = st.seconds_trace = 1e-9;
-    if (stats) *stats = st;
     return RT_OK;
 }
 
@@ -960,7 +897,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         if (!finite3(spheres[i].center) || !std::isfinite(spheres[i].radius) || spheres[i].radius < 0.0)
             return fail(RT_ERR_INVALID, "sphere %zu: non-finite or negative geometry", i);
     }
-    {   // (in pieces on the build threads; the first offending triangle is the one reported, as a plain loop would)
+    try {   // (in pieces on the build threads; the first offending triangle is the one reported, as a plain loop would)
         constexpr size_t PIECE = 65536;
         const size_t n_pieces = (n_triangles + PIECE - 1) / PIECE;
         std::vector<size_t> first_bad(n_pieces, SIZE_MAX);
@@ -976,6 +913,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             if (triangles[i].material >= n_materials) return fail(RT_ERR_INVALID, "triangle %zu: material out of range", i);
             return fail(RT_ERR_INVALID, "triangle %zu: non-finite vertex", i);
         }
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_OOM, "scene validation failed: %s", e.what());
     }
     DeviceGuard dg;
     int rc = select_device(device);
@@ -989,6 +928,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
     rt_scene* sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OOM, "out of host memory");
     sc->device = device;
+    refresh_tuning(sc);
     struct Guard {
         rt_scene* s;
         ~Guard() { if (s) rt_scene_destroy(s); }
@@ -1022,9 +962,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         BvhResult bvh;
         // RT_HIP_BUILDER=lbvh: Morton-order build on the device (milliseconds; lower tree quality); default: binned SAH
         // on the host.  The device build declines tiny scenes and trees deeper than the traversal stacks.
-        const char* be = getenv("RT_HIP_BUILDER");
         bool built = false;
-        if (be && strcmp(be, "lbvh") == 0) {
+        if (sc->tune.builder == "lbvh") {
             std::string berr;
             const int brc = build_bvh_device(boxes, n_spheres, bvh, berr);
             if (brc < 0) return fail(RT_ERR_HIP, "device BVH build: %s", berr.c_str());
@@ -1110,8 +1049,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         // Node format: conservative f32 boxes (default; 64 B/node) or exact f64 boxes (128 B/node).
         // RT_HIP_NODE_BOXES=f64 forces the latter (the two must give identical hits; tests compare).
         // Coordinates beyond f32 range also fall back to f64 boxes.
-        const char* nb = getenv("RT_HIP_NODE_BOXES");
-        bool use32 = !(nb && strcmp(nb, "f64") == 0);
+        const std::string& nb = sc->tune.node_boxes;
+        bool use32 = nb != "f64";
         for (const Node64& nd : bvh.nodes)
             for (int k = 0; k < 3 && use32; ++k) {
                 const double m = std::max(std::max(std::fabs(nd.lo_l[k]), std::fabs(nd.hi_l[k])),
@@ -1136,8 +1075,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             // enough for this scene (RT_HIP_NODE_BOXES=f32 disables; =q16 forces the grid and keeps the
             // BVH2; =w4 forces the grid and the BVH4), and on the same grid the BVH4 that bounce rays use
             std::vector<Node16> n16;
-            const bool force4 = nb && strcmp(nb, "w4") == 0;
-            const bool force16 = (nb && strcmp(nb, "q16") == 0) || force4, no16 = nb && strcmp(nb, "f32") == 0;
+            const bool force4 = nb == "w4";
+            const bool force16 = nb == "q16" || force4, no16 = nb == "f32";
             if (!no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
                 for (int k = 0; k < 3; ++k) sc->d.grid_inv_cell[k] = 1.0 / (double)sc->d.grid.cell[k];
                 if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
@@ -1148,13 +1087,13 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                     n_nodes4 = n4.size();
                     use4 = true;
                 }
-                if (getenv("RT_HIP_DEBUG_UTIL")) {
+                if (sc->tune.debug) {
                     fprintf(stderr, "[rt_hip] BVH4: %zu nodes from %zu BVH2 nodes, stack need %u, %s\n", n4.size(), bvh.nodes.size(), need,
                             use4 ? "used" : "not used");
                 }
             }
             // no usable grid: the BVH4 with f32 boxes (RT_HIP_NODE_BOXES=f32 keeps the BVH2 for A/B, =w4f forces this one)
-            const bool force4f = nb && strcmp(nb, "w4f") == 0;
+            const bool force4f = nb == "w4f";
             if ((!use16 && !no16) || force4f) {
                 uint32_t need = 0;
                 if (widen_nodes_f32(bvh.nodes, n4f, need) && need <= (uint32_t)BVH4_MAX_STACK) {
@@ -1237,11 +1176,24 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             // what the BVH4 walk touches: with it inside the 256 MB Infinity Cache the walk is bound by instruction issue and
             // every lane fetches (walk_body); RT_HIP_ALL_LANES_LOAD=0|1 overrides
             const size_t walked = n_nodes4 * (use4f ? sizeof(Node4f) : sizeof(Node4)) + n_triangles * sizeof(TriGeom) + n_spheres * sizeof(SphGeom);
-            const char* al = getenv("RT_HIP_ALL_LANES_LOAD");
-            sc->d.all_lanes_load = al ? (atoi(al) != 0) : (use4 && walked <= (size_t)256 << 20);
+            sc->d.all_lanes_load = sc->tune.all_lanes_load >= 0 ? (uint32_t)sc->tune.all_lanes_load : (use4 && walked <= (size_t)256 << 20);
         }
         HIPCHK(hipDeviceSynchronize());
         const double tb2 = now_s();
+        {   // The allocation-free entry point must not be the first to run its kernels on this device: the first launch of a
+            // kernel loads its code object and the first launch of a walk kernel asks the runtime for its occupancy
+            // (LaunchCtx::walk_slots), and either may allocate.  One ray through the same three launches, here, where
+            // allocating is allowed; the scratch array is scratch.
+            std::lock_guard<std::mutex> dl(g_device_mu[device]);
+            void* tmp = nullptr;
+            HIPCHK(hipMalloc(&tmp, 256));
+            struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{tmp};
+            HIPCHK(hipMemset(tmp, 0, 256));
+            const rt_ray one = {{0.0, 0.0, 0.0}, {0.0, 0.0, 1.0}};
+            HIPCHK(hipMemcpy(tmp, &one, sizeof(one), hipMemcpyHostToDevice));
+            if ((rc = trace_noalloc_queued(sc, (const rt_ray*)tmp, 1, 0.001, 1.0, (rt_hit*)((char*)tmp + 128), nullptr))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+        }
 
         sc->info.n_prims = n_prims;
         sc->info.n_nodes = bvh.nodes.size();
@@ -1257,6 +1209,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.upload_seconds = tb2 - tb1;
     } catch (const std::bad_alloc&) {
         return fail(RT_ERR_OOM, "out of host memory while flattening the scene");
+    } catch (const std::exception& e) {       // (nothing may cross the C ABI: a thread that cannot start, a length error ...)
+        return fail(RT_ERR_INVALID, "scene creation failed: %s", e.what());
     }
     guard.s = nullptr;
     *out = sc;
@@ -1282,6 +1236,9 @@ void rt_scene_destroy(rt_scene* sc) {
         if (sc->pv_rgba8) (void)hipFree(sc->pv_rgba8);
         for (void* p : sc->io)
             if (p) (void)hipFree(p);
+        if (sc->mg_sum) (void)hipFree(sc->mg_sum);
+        if (sc->mg_sum32) (void)hipFree(sc->mg_sum32);
+        if (sc->mg_stream) (void)hipStreamDestroy(sc->mg_stream);
         for (void* p : sc->allocs) (void)hipFree(p);
     }
     (void)hipGetLastError();
@@ -1306,6 +1263,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     DeviceGuard dg;
     int rc = select_device(sc->device);
     if (rc) return rc;
+    refresh_tuning(sc);
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     if ((rc = ensure_workspace(sc, chunk))) return rc;
     Workspace& w = sc->ws[0];
@@ -1324,7 +1282,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
         const QueueGeom qg = {nullptr, shard_cap_for(m), m};
         launch_prepare_rays(d_rays, qg, w.q[0], stream);
         HIPCHK(hipEventRecord(w.ev[0], stream));
-        launch_walk(sc->d, w.q[0], qg, m, t_min, t_max, w.hb, want_stats, want_stats ? sg : nullptr, stream, 0, &w.ovf);
+        launch_walk(sc->lctx, sc->d, w.q[0], qg, m, t_min, t_max, w.hb, want_stats, want_stats ? sg : nullptr, stream, 0, &w.ovf);
         HIPCHK(hipEventRecord(w.ev[1], stream));
         launch_pack_hits(w.hb, qg, d_hits, stream);
         HIPCHK(hipMemcpyAsync(out + off, d_hits, m * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
@@ -1365,30 +1323,7 @@ int rt_trace_closest_noalloc(const rt_scene* csc, const rt_ray* d_rays, size_t n
     DeviceGuard dg;
     int rc = select_device(sc->device);
     if (rc) return rc;
-    unsigned char* base = nullptr;                      // the device address kept at set-up (rt_scene_create)
-    if ((rc = noalloc_scratch_for(sc->device, &base))) return rc;
-    // carve the array: every kernel below gets these pointers as arguments, like the workspace of rt_trace_closest
-    double* dp = (double*)base;
-    uint32_t* up = (uint32_t*)(base + NOALLOC_DOUBLES * sizeof(double));
-    RayQueue q{};
-    HitBuf hb{};
-    for (int c = 0; c < 3; ++c) q.o[c] = dp + (size_t)c * NOALLOC_SLOTS;
-    for (int c = 0; c < 3; ++c) q.d[c] = dp + (size_t)(3 + c) * NOALLOC_SLOTS;
-    for (int c = 0; c < 3; ++c) q.thr[c] = nullptr;     // the traversal never touches the throughput
-    hb.t = dp + 6 * NOALLOC_SLOTS;
-    hb.bu = dp + 7 * NOALLOC_SLOTS;
-    hb.bv = dp + 8 * NOALLOC_SLOTS;
-    q.pid = up;
-    hb.prim = up + NOALLOC_SLOTS;
-    hipStream_t stream = (hipStream_t)stream_;
-    // Nothing has to start at zero: k_prepare_rays writes every queue slot the traversal reads, the traversal writes t and
-    // prim of every one of them (bu / bv are not read by k_pack_hits), and no counter is involved (stats are off).
-    const QueueGeom qg = {nullptr, shard_cap_for(n), (uint32_t)n};
-    launch_prepare_rays(d_rays, qg, q, stream);
-    launch_walk(sc->d, q, qg, (uint32_t)n, t_min, t_max, hb, false, nullptr, stream);
-    launch_pack_hits(hb, qg, d_hits, stream);
-    HIPCHK(hipGetLastError());
-    return RT_OK;
+    return trace_noalloc_queued(sc, d_rays, n, t_min, t_max, d_hits, (hipStream_t)stream_);
 }
 
 int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_index, int jitter, uint64_t seed,
@@ -1404,6 +1339,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     std::lock_guard<std::mutex> sl(sc->mu);
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
+    refresh_tuning(sc);
     if ((rc = ensure_workspace(sc, npix))) return rc;
     Workspace& w = sc->ws[0];
     rt_hit* d_hits = nullptr;
@@ -1426,10 +1362,10 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     const QueueGeom qm = {nullptr, shard_cap_for(npix), (uint32_t)npix};
     launch_raygen(pp, qm, w.q[0], stream);
     // RT_HIP_PRIMARY_PACKET=1 (tests): the coherent-wave kernel that rt_render uses for camera rays, on the same rays
-    if (getenv("RT_HIP_PRIMARY_PACKET") && packet_supported(sc->d))
+    if (sc->tune.primary_packet && packet_supported(sc->d))
         launch_trace_packet(sc->d, nullptr, w.q[0], qm, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, nullptr);
     else
-        launch_walk(sc->d, w.q[0], qm, (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, 0, &w.ovf);
+        launch_walk(sc->lctx, sc->d, w.q[0], qm, (uint32_t)npix, cam->t_min, cam->t_max, w.hb, false, nullptr, stream, 0, &w.ovf);
     launch_pack_hits(w.hb, qm, d_hits, stream);
     HIPCHK(hipMemcpyAsync(out, d_hits, npix * sizeof(rt_hit), hipMemcpyDeviceToHost, stream));
     if (rays_out) {
@@ -1453,6 +1389,7 @@ int rt_render_accumulate_device(const rt_scene* csc, const rt_camera* cam, const
     std::lock_guard<std::mutex> sl(sc->mu);
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
+    refresh_tuning(sc);
     return render_into(sc, cam, opts, d_rgb_sum, (hipStream_t)stream, stats);
 }
 
@@ -1479,6 +1416,7 @@ int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, do
     std::lock_guard<std::mutex> sl(sc->mu);
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
+    refresh_tuning(sc);
     const size_t nval = (size_t)cam->width * cam->height * 3;
     double* d_sum = nullptr;
     if ((rc = scene_io(sc, 0, nval, &d_sum))) return rc;
@@ -1514,6 +1452,7 @@ int rt_render_pass(const rt_scene* csc, const rt_camera* cam, uint32_t n_samples
     std::lock_guard<std::mutex> sl(sc->mu);
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
+    refresh_tuning(sc);
     const size_t npix = (size_t)cam->width * cam->height;
     const bool first = total_samples == n_samples;               // sweep 1: the old frame has weight 0 (src/window.rs:293-295)
     if (sc->pv_pixels != npix) {                                 // frame buffers live with the scene: no allocation per pass
@@ -1595,11 +1534,21 @@ int rccl_load() {
     g_rccl = r;
     return RT_OK;
 }
-constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;      // ncclFloat64, ncclSum (rccl.h)
+constexpr int NCCL_FLOAT = 7, NCCL_DOUBLE = 8, NCCL_SUM = 0;      // ncclFloat32, ncclFloat64, ncclSum (rccl.h)
 }  // namespace
 
+static int render_multi_impl(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,
+                             double* out_rgb_mean, rt_stats* stats);
 int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,
                     double* out_rgb_mean, rt_stats* stats) {
+    try {
+        return render_multi_impl(scenes, n_devices, cam, opts, out_rgb_mean, stats);
+    } catch (const std::exception& e) {              // (host allocation of the bookkeeping vectors; nothing may cross the C ABI)
+        return fail(RT_ERR_OOM, "rt_render_multi: %s", e.what());
+    }
+}
+static int render_multi_impl(rt_scene* const* scenes, uint32_t n_devices, const rt_camera* cam, const rt_opts* opts,
+                             double* out_rgb_mean, rt_stats* stats) {
     if (!scenes || !opts || !out_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
     if (n_devices < 1 || n_devices > 64) return fail(RT_ERR_INVALID, "n_devices must be 1..64");
     int rc = check_camera(cam);
@@ -1629,48 +1578,97 @@ int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera
     }
     const size_t nval = (size_t)cam->width * cam->height * 3;
     const uint32_t stride0 = opts->sample_stride ? opts->sample_stride : 1;
-    // device g renders the frame's samples g, g + N, g + 2N, ... (scene replicated, sample-index partition)
-    struct PerDev { double* d_sum = nullptr; hipStream_t stream = nullptr; int rc = RT_OK; std::string err; rt_stats st{}; uint32_t spp = 0; };
+    if (opts->flags & ~(uint32_t)RT_OPT_REDUCE_F32) return fail(RT_ERR_INVALID, "unknown rt_opts.flags bits 0x%x", opts->flags);
+    const bool f32 = (opts->flags & RT_OPT_REDUCE_F32) != 0;
+    // device g renders the frame's samples g, g + N, g + 2N, ... (scene replicated, sample-index partition) into the sum
+    // buffer its scene owns, on the stream its scene owns; every worker holds its device's and its scene's mutex until the
+    // exchange and the read-back are through, so the buffers cannot be reused under a running reduce
+    struct PerDev { int rc = RT_OK; std::string err; rt_stats st{}; uint32_t spp = 0; };
     std::vector<PerDev> pd(n_devices);
+    std::vector<std::unique_lock<std::mutex>> dev_locks(n_devices), scene_locks(n_devices);
+    for (uint32_t g = 0; g < n_devices; ++g) {      // in device order: two concurrent calls cannot deadlock on each other
+        std::vector<uint32_t> order(n_devices);
+        for (uint32_t j = 0; j < n_devices; ++j) order[j] = j;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return devs[a] < devs[b]; });
+        const uint32_t k = order[g];
+        dev_locks[k] = std::unique_lock<std::mutex>(g_device_mu[devs[k]]);
+        scene_locks[k] = std::unique_lock<std::mutex>(scenes[k]->mu);
+    }
     auto worker = [&](uint32_t g) {
         PerDev& P = pd[g];
         rt_scene* sc = scenes[g];
-        std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
-        std::lock_guard<std::mutex> sl(sc->mu);
         auto bail = [&](int code) { P.rc = code; P.err = g_err; };
-        if (int r = select_device(sc->device)) return bail(r);
-        if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_HIP, "hipStreamCreate failed on device %d", sc->device)); }
-        if (hipMalloc((void**)&P.d_sum, nval * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_OOM, "hipMalloc of the radiance sums failed on device %d", sc->device)); }
-        if (hipMemsetAsync(P.d_sum, 0, nval * sizeof(double), P.stream) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_HIP, "hipMemsetAsync failed")); }
-        P.spp = opts->spp > g ? (opts->spp - g + n_devices - 1) / n_devices : 0;
-        if (P.spp) {
-            rt_opts o = *opts;
-            o.spp = P.spp;
-            o.sample_offset = opts->sample_offset + g * stride0;
-            o.sample_stride = stride0 * n_devices;
-            o.device = sc->device;
-            if (int r = render_into(sc, cam, &o, P.d_sum, P.stream, &P.st)) return bail(r);
+        try {
+            if (int r = select_device(sc->device)) return bail(r);
+            refresh_tuning(sc);
+            if (!sc->mg_stream && hipStreamCreateWithFlags(&sc->mg_stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                sc->mg_stream = nullptr;
+                return bail(fail(RT_ERR_HIP, "hipStreamCreate failed on device %d", sc->device));
+            }
+            if (sc->mg_cap < nval) {
+                if (sc->mg_sum) (void)hipFree(sc->mg_sum);
+                sc->mg_sum = nullptr; sc->mg_cap = 0;
+                if (hipMalloc((void**)&sc->mg_sum, nval * sizeof(double)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sc->mg_sum = nullptr;
+                    return bail(fail(RT_ERR_OOM, "hipMalloc of the radiance sums failed on device %d", sc->device));
+                }
+                sc->mg_cap = nval;
+            }
+            if (f32 && sc->mg_cap32 < nval) {
+                if (sc->mg_sum32) (void)hipFree(sc->mg_sum32);
+                sc->mg_sum32 = nullptr; sc->mg_cap32 = 0;
+                if (hipMalloc((void**)&sc->mg_sum32, nval * sizeof(float)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sc->mg_sum32 = nullptr;
+                    return bail(fail(RT_ERR_OOM, "hipMalloc of the f32 sums failed on device %d", sc->device));
+                }
+                sc->mg_cap32 = nval;
+            }
+            if (hipMemsetAsync(sc->mg_sum, 0, nval * sizeof(double), sc->mg_stream) != hipSuccess) { (void)hipGetLastError(); return bail(fail(RT_ERR_HIP, "hipMemsetAsync failed")); }
+            P.spp = opts->spp > g ? (opts->spp - g + n_devices - 1) / n_devices : 0;
+            if (P.spp) {
+                rt_opts o = *opts;
+                o.spp = P.spp;
+                o.sample_offset = opts->sample_offset + g * stride0;
+                o.sample_stride = stride0 * n_devices;
+                o.device = sc->device;
+                o.flags = 0;
+                if (int r = render_into(sc, cam, &o, sc->mg_sum, sc->mg_stream, &P.st)) return bail(r);
+            }
+            if (f32) {
+                launch_narrow_f32(sc->mg_sum, sc->mg_sum32, nval, sc->mg_stream);
+                if (hipGetLastError() != hipSuccess) return bail(fail(RT_ERR_HIP, "narrowing the sums failed on device %d", sc->device));
+            }
+        } catch (const std::exception& e) {          // (nothing may leave a worker thread, nor the C ABI)
+            bail(fail(RT_ERR_OOM, "device %d: %s", sc->device, e.what()));
         }
     };
     {
         std::vector<std::thread> th;
-        for (uint32_t g = 1; g < n_devices; ++g) th.emplace_back(worker, g);
+        uint32_t started = 1;
+        try {
+            for (uint32_t g = 1; g < n_devices; ++g, ++started) th.emplace_back(worker, g);
+        } catch (const std::system_error&) {         // no thread to be had: the caller's thread takes the remaining devices in turn
+        }
         worker(0);
+        for (uint32_t g = started; g < n_devices; ++g) worker(g);
         for (auto& t : th) t.join();
     }
-    int first_bad = -1;
-    for (uint32_t g = 0; g < n_devices; ++g)
-        if (pd[g].rc && first_bad < 0) first_bad = (int)g;
-    auto cleanup = [&]() {
+    // whatever happened, nothing of this call may still run on a scene's stream when the locks go
+    auto drain = [&]() {
         for (uint32_t g = 0; g < n_devices; ++g) {
             if (hipSetDevice(devs[g]) != hipSuccess) { (void)hipGetLastError(); continue; }
-            if (pd[g].stream) { (void)hipStreamSynchronize(pd[g].stream); (void)hipStreamDestroy(pd[g].stream); }
-            if (pd[g].d_sum) (void)hipFree(pd[g].d_sum);
+            if (scenes[g]->mg_stream) (void)hipStreamSynchronize(scenes[g]->mg_stream);
         }
         (void)hipGetLastError();
     };
+    int first_bad = -1;
+    for (uint32_t g = 0; g < n_devices; ++g)
+        if (pd[g].rc && first_bad < 0) first_bad = (int)g;
     if (first_bad >= 0) {
-        cleanup();
+        drain();
         g_err = "device " + std::to_string(devs[first_bad]) + ": " + pd[first_bad].err;
         return pd[first_bad].rc;
     }
@@ -1680,25 +1678,31 @@ int rt_render_multi(rt_scene* const* scenes, uint32_t n_devices, const rt_camera
         int r = g_rccl.GroupStart();
         for (uint32_t g = 0; g < n_devices && r == 0; ++g) {
             if (hipSetDevice(devs[g]) != hipSuccess) { (void)hipGetLastError(); r = -1; break; }
-            r = g_rccl.Reduce(pd[g].d_sum, pd[g].d_sum, nval, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], pd[g].stream);
+            rt_scene* sc = scenes[g];
+            r = f32 ? g_rccl.Reduce(sc->mg_sum32, sc->mg_sum32, nval, NCCL_FLOAT, NCCL_SUM, 0, comms[g], sc->mg_stream)
+                    : g_rccl.Reduce(sc->mg_sum, sc->mg_sum, nval, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], sc->mg_stream);
         }
         const int r2 = g_rccl.GroupEnd();
         if (r == 0) r = r2;
         if (r != 0) {
-            cleanup();
+            drain();
             return fail(RT_ERR_HIP, "ncclReduce failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "hipSetDevice");
         }
     }
     rc = select_device(devs[0]);
     if (!rc) {
-        launch_resolve(pd[0].d_sum, pd[0].d_sum, nval, (double)opts->spp, pd[0].stream);
-        hipError_t e = hipMemcpyAsync(out_rgb_mean, pd[0].d_sum, nval * sizeof(double), hipMemcpyDeviceToHost, pd[0].stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(pd[0].stream);
+        rt_scene* sc = scenes[0];
+        if (f32) launch_resolve_f32(sc->mg_sum32, sc->mg_sum, nval, (double)opts->spp, sc->mg_stream);
+        else launch_resolve(sc->mg_sum, sc->mg_sum, nval, (double)opts->spp, sc->mg_stream);
+        hipError_t e = hipMemcpyAsync(out_rgb_mean, sc->mg_sum, nval * sizeof(double), hipMemcpyDeviceToHost, sc->mg_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(sc->mg_stream);
         if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(RT_ERR_HIP, "read-back of the reduced frame failed: %s", hipGetErrorName(e)); }
     }
     if (stats)
         for (uint32_t g = 0; g < n_devices; ++g) stats[g] = pd[g].st;
-    cleanup();
+    const std::string keep = g_err;
+    drain();
+    if (rc) g_err = keep;
     return rc;
 }
 

@@ -73,12 +73,20 @@ struct StackOverflow {
     uint32_t rows_cap;     // rows available
     uint32_t waves;        // columns available / 64: the persistent launch never has more waves than this
 };
-uint32_t stack_overflow_rows(const DScene& S);       // rows a StackOverflow buffer needs for this scene (0: none)
-void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+constexpr uint32_t OVF_LDS_ROWS = 32;                // stack rows the overflow-stack kernels keep in LDS
+// What the walk launchers keep per scene (= per device) beyond their arguments; filled and read under the device's mutex.
+struct LaunchCtx {
+    bool refill = true;                  // persistent launches with lane refill (false: one chunk per wave; tests)
+    unsigned refill_slots = 0;           // tests: number of persistent waves (0 = what the device holds)
+    uint32_t ovf_lds_rows = OVF_LDS_ROWS;    // tests lower it so that small scenes reach the overflow rows
+    unsigned walk_slots[2][2][5] = {};   // resident waves of the scene's walk kernel by [STATS][SHADE][stack size class]; 0 = not asked yet
+};
+uint32_t stack_overflow_rows(const DScene& S, uint32_t lds_rows);       // rows a StackOverflow buffer needs for this scene (0: none)
+void launch_walk(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
                  bool stats, unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0, const StackOverflow* ovf = nullptr);
 // K1 + K2-4, persistent: traces AND shades the queue's paths (entries at depth depth0), bounce after bounce inside
 // the kernel, until every path has ended (radiance slots written)
-void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
+void launch_walk_shade(LaunchCtx& ctx, const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
                        double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
                        unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate = 0, const StackOverflow* ovf = nullptr);
 // K1p: closest hit for coherent waves (camera rays; always a dense queue): wave-level packet traversal through the scalar cache
@@ -107,6 +115,9 @@ void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint
                        double* d_rgb_sum, uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s);
 // K5b: mean = sum / total_spp
 void launch_resolve(const double* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
+// the f32 exchange of rt_render_multi: narrow a device's f64 sums; mean = (f64)sum32 / total_spp on the root
+void launch_narrow_f32(const double* d_in, float* d_out, size_t n_values, hipStream_t s);
+void launch_resolve_f32(const float* d_sum, double* d_mean, size_t n_values, double total_spp, hipStream_t s);
 // output stage: 8-bit gamma-encoded frame from a resolved one (src/vec3.rs:71-97)
 void launch_gamma8(const double* d_mean, size_t n_values, uint8_t* d_out, hipStream_t s);
 // preview blend of one pass into the float and the 8-bit linear RGBA frame (src/window.rs:277-310)

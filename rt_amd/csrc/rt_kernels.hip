@@ -312,12 +312,7 @@ struct WalkShade {
 // triangles) leave 2.5-3 waves per SIMD where the registers allow 4, and these walks are bound by memory latency, i.e. by
 // the number of waves in flight.  Real traversals stay far below the worst case the builder computes, so the overflow
 // rows are touched by few lanes.
-constexpr uint32_t OVF_LDS_ROWS = 32;
-static uint32_t ovf_lds_rows() {
-    const char* e = getenv("RT_HIP_OVF_LDS_ROWS");
-    const int v = e ? atoi(e) : 0;
-    return v >= 4 && v <= (int)OVF_LDS_ROWS ? (uint32_t)v : OVF_LDS_ROWS;
-}
+static_assert(OVF_LDS_ROWS == 32, "the OVF kernels' LDS stack");      // (rt_kernels.h; LaunchCtx::ovf_lds_rows lowers it for tests)
 // MODE of a walk kernel: plain; OVF (above); ALL = every lane fetches (below, at the loads) — for scenes that live in the
 // caches, which are not the ones with deep trees, so the two are never combined.  (A run-time switch instead of an instance
 // per mode costs two registers, and the kernel sits exactly at the count that lets a fifth wave of another kernel onto
@@ -374,12 +369,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
     uint32_t cur = REF_EMPTY;
     int sp = 0;
     uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0, n_seg = 0;
-#ifdef RT_TIMING
-    unsigned long long tm_issue = 0, tm_wait = 0, tm_node = 0, tm_prim = 0, tm_refill = 0, tm_n_node = 0, tm_n_prim = 0, tm_last = clock64();
-#define RT_STAMP(acc) { const unsigned long long now_ = clock64(); acc += now_ - tm_last; tm_last = now_; }
-#else
-#define RT_STAMP(acc)
-#endif
 
     for (;;) {
         const bool at_node = !(cur & REF_LEAF);                 // REF_EMPTY has the leaf bit set
@@ -439,7 +428,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 chunk_pos += take;
                 more = chunk_pos < 64u || next_chunk < n_chunks;
             }
-            RT_STAMP(tm_refill)
             if (!__ballot(busy)) break;
             continue;
         }
@@ -481,13 +469,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             if (tri_leaf || (F32_NODES && at_node)) e = p[4];
             if (F32_NODES && at_node) { f = p[5]; g = p[6]; }
         }
-#ifdef RT_TIMING
-        RT_STAMP(tm_issue)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        RT_STAMP(tm_wait)
-        if (__ballot(at_node)) ++tm_n_node;
-        if (__ballot(at_leaf)) ++tm_n_prim;
-#endif
         if (at_node) {
             if (STATS) ++n_nodes;
             if constexpr (W4) {
@@ -548,10 +529,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 }
             }
         }
-#ifdef RT_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        RT_STAMP(tm_node)
-#endif
         if (at_leaf) {
             if (STATS) { ++n_prims; ++n_leaves; }
             if (tri_leaf) {                                           // TriGeom: a, e1, e2 (9 doubles), prim
@@ -575,10 +552,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             const uint32_t next_ = W4 ? ((cur & REF_SPHERE) ? (uint32_t)(sizeof(SphGeom) / 16) : (uint32_t)(sizeof(TriGeom) / 16)) : 1u;
             cur = (cur & 0x30000000u) ? cur - 0x10000000u + next_ : (sp ? RT_POP() : REF_EMPTY);
         }
-#ifdef RT_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        RT_STAMP(tm_prim)
-#endif
     }
 #undef RT_PUSH
 #undef RT_POP
@@ -600,11 +573,6 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             atomicAdd(&counters[STAT_PRIMS], b);
             atomicAdd(&counters[STAT_ITERS], (unsigned long long)n_iters);
             atomicAdd(&counters[STAT_LEAVES], c);
-#ifdef RT_TIMING
-            atomicAdd(&counters[8], tm_issue); atomicAdd(&counters[9], tm_wait); atomicAdd(&counters[10], tm_node);
-            atomicAdd(&counters[11], tm_prim); atomicAdd(&counters[12], tm_refill); atomicAdd(&counters[13], tm_n_node);
-            atomicAdd(&counters[14], tm_n_prim);
-#endif
         }
     }
 }
@@ -691,32 +659,16 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
     uint32_t prim = RT_MISS;
     uint32_t n_nodes = 0, n_prims = 0, w_nodes = 0, w_prims = 0;      // per lane / per wave (records the wave fetched)
     uint32_t w_dead = 0;                                              // node records no lane's ray entered a child of
-#ifdef RT_TIMING
-    // (instrumented builds only: cycles of the wave per phase — generation, node steps, primitive steps, shading)
-    unsigned long long pk_t0 = clock64(), pk_gen = 0, pk_node = 0, pk_prim = 0, pk_shade = 0, pk_last = 0;
-    uint32_t w_nodes_t = 0, w_prims_t = 0;
-#define RT_PK_STAMP(acc) { const unsigned long long now_ = clock64(); acc += now_ - pk_last; pk_last = now_; }
-#else
-#define RT_PK_STAMP(acc)
-#endif
     unsigned long long mask = __ballot(active);
     // Camera rays of a few neighbouring pixels nearly always agree on the sign of each direction component; then the
     // near and far plane of every box are the same for the whole wave and are picked with scalar selects.
     const unsigned long long neg_x = __ballot(active && rb.ix < 0.f), neg_y = __ballot(active && rb.iy < 0.f),
                              neg_z = __ballot(active && rb.iz < 0.f);
     const bool same_signs = (neg_x == 0 || neg_x == mask) && (neg_y == 0 || neg_y == mask) && (neg_z == 0 || neg_z == mask);
-    const uint32_t sxn_u = __builtin_amdgcn_readfirstlane(neg_x != 0 ? 1u : 0u), syn_u = __builtin_amdgcn_readfirstlane(neg_y != 0 ? 1u : 0u),
-                   szn_u = __builtin_amdgcn_readfirstlane(neg_z != 0 ? 1u : 0u);
     uint32_t cur = (mask && S.root != REF_EMPTY) ? S.root : REF_EMPTY;
     int sp = 0;
-#ifdef RT_TIMING
-    pk_last = pk_t0;
-    RT_PK_STAMP(pk_gen)
-#endif
 
     while (cur != REF_EMPTY) {
-        const bool was_leaf_ = (cur & REF_LEAF) != 0;
-        (void)was_leaf_;
         if (!(cur & REF_LEAF)) {
             const u32x16 nd = uload16(&S.nodes32[cur]);
             const uint32_t cl = nd[12], cr = nd[13];
@@ -727,14 +679,14 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             float tl = 0.f, tr = 0.f, tfl = 0.f, tfr = 0.f;      // entry and exit parameter of the two boxes
             // both boxes tested without masked regions (the node is wave-uniform, the arithmetic is per lane)
             if (same_signs) {
-                // four scalar selects per axis behind one compare (the planes sit in SGPRs; written out because the
-                // compiler sets the condition code again before every select)
+                // four scalar selects per axis behind one compare of the axis' lane mask (the planes sit in SGPRs; written
+                // out because the compiler sets the condition code again before every select)
                 uint32_t n_l[3], f_l[3], n_r[3], f_r[3];
-#define RT_PICK(j, flag) asm("s_cmp_lg_u32 %4, 0\n\ts_cselect_b32 %0, %6, %5\n\ts_cselect_b32 %1, %5, %6\n\t" \
+#define RT_PICK(j, flag) asm("s_cmp_lg_u64 %4, 0\n\ts_cselect_b32 %0, %6, %5\n\ts_cselect_b32 %1, %5, %6\n\t" \
                              "s_cselect_b32 %2, %8, %7\n\ts_cselect_b32 %3, %7, %8" \
                              : "=&s"(n_l[j]), "=&s"(f_l[j]), "=&s"(n_r[j]), "=&s"(f_r[j]) \
                              : "s"(flag), "s"(nd[j]), "s"(nd[3 + j]), "s"(nd[6 + j]), "s"(nd[9 + j]) : "scc")
-                RT_PICK(0, sxn_u); RT_PICK(1, syn_u); RT_PICK(2, szn_u);
+                RT_PICK(0, neg_x); RT_PICK(1, neg_y); RT_PICK(2, neg_z);
 #undef RT_PICK
                 const float nl[3] = {__uint_as_float(n_l[0]), __uint_as_float(n_l[1]), __uint_as_float(n_l[2])};
                 const float fl[3] = {__uint_as_float(f_l[0]), __uint_as_float(f_l[1]), __uint_as_float(f_l[2])};
@@ -752,9 +704,6 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             const unsigned long long mr = cr != REF_EMPTY ? mask & rb.accept_mask(tr, tfr) : 0ull;
             if (STATS && ((mask >> lane) & 1ull)) ++n_nodes;
             if (STATS) ++w_nodes;
-#ifdef RT_TIMING
-            ++w_nodes_t;
-#endif
             if (ml && mr) {
                 // near child first, by majority of the lanes that care (a ray in both children votes for the nearer one)
                 const unsigned long long both = ml & mr, le = __builtin_amdgcn_fcmpf(tl, tr, 5 /* LLVM FCMP_OLE */);
@@ -770,15 +719,12 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                 ++sp;
                 cur = left_first ? cl : cr;
                 mask = left_first ? ml : mr;
-                RT_PK_STAMP(pk_node)
                 continue;
             } else if (ml) {
                 cur = cl; mask = ml;
-                RT_PK_STAMP(pk_node)
                 continue;
             } else if (mr) {
                 cur = cr; mask = mr;
-                RT_PK_STAMP(pk_node)
                 continue;
             }
             if (STATS) ++w_dead;
@@ -787,9 +733,6 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
             const bool mine = (mask >> lane) & 1ull;
             if (STATS && mine) n_prims += count;
             if (STATS) w_prims += count;
-#ifdef RT_TIMING
-            w_prims_t += count;
-#endif
             if (cur & REF_SPHERE) {
                 for (uint32_t k = 0; k < count; ++k) {
                     const u32x16 g = uload16(&S.sphs[first + k]);
@@ -817,13 +760,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         const PacketEntry e = stack[sp];
         cur = __builtin_amdgcn_readfirstlane(e.ref);
         mask = ((unsigned long long)__builtin_amdgcn_readfirstlane(e.mask_hi) << 32) | __builtin_amdgcn_readfirstlane(e.mask_lo);
-#ifdef RT_TIMING
-        if (was_leaf_) RT_PK_STAMP(pk_prim) else RT_PK_STAMP(pk_node)
-#endif
     }
-#ifdef RT_TIMING
-    RT_PK_STAMP(pk_prim)
-#endif
     if (FUSE) {
         bool alive = false;
         D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
@@ -839,9 +776,6 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
         hb.bu[i] = bu;
         hb.bv[i] = bv;
     }
-#ifdef RT_TIMING
-    RT_PK_STAMP(pk_shade)
-#endif
     if (STATS) {
         unsigned long long a = n_nodes, b = n_prims;
         for (int off = 32; off; off >>= 1) {
@@ -857,14 +791,6 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
 
         }
     }
-#ifdef RT_TIMING
-    // one wave in 64 reports (every wave reporting would queue a million atomics on five addresses and stretch what is measured)
-    if (counters && lane == 0 && (blockIdx.x & 63u) == 0u) {
-        atomicAdd(&counters[8], pk_gen); atomicAdd(&counters[9], pk_node); atomicAdd(&counters[10], pk_prim);
-        atomicAdd(&counters[11], pk_shade); atomicAdd(&counters[12], 1ull);
-        atomicAdd(&counters[13], (unsigned long long)w_nodes_t); atomicAdd(&counters[14], (unsigned long long)w_prims_t);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1095,6 +1021,17 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* me
     if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
 }
 
+// The f32 form of the multi-GPU exchange ("ncclReduce(sum, f32, W*H*3)"): a device's f64 sums are narrowed
+// once, the f32 buffers are summed over xGMI (half the bytes), the root divides.  Only the cross-device sum is f32.
+__global__ __launch_bounds__(BLOCK) void k_narrow_f32(const double* in, float* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+__global__ __launch_bounds__(BLOCK) void k_resolve_f32(const float* sum, double* mean, size_t n, double total_spp) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) mean[i] = (double)sum[i] / total_spp;
+}
+
 // f64::round (half away from zero, like C's round) of a value already in [0, 255]
 __device__ __forceinline__ uint8_t round_u8(double x) { return (uint8_t)round(x); }
 __device__ __forceinline__ double clamp_colour(double c) {      // the reference panics outside [0, 1] (src/vec3.rs:44-63): clamp; NaN -> 0
@@ -1198,43 +1135,33 @@ static unsigned resident_waves(K kernel, size_t lds) {
         return 256u * 8u;
     return (unsigned)pr.multiProcessorCount * (unsigned)per_cu;
 }
-// one-chunk-per-wave launches instead of persistent ones (tests, A/B): RT_HIP_NO_REFILL=1; RT_HIP_REFILL_SLOTS=<n> sets
-// the number of persistent waves
-static bool refill_enabled() { const char* n = getenv("RT_HIP_NO_REFILL"); return !(n && atoi(n) == 1); }
-static unsigned refill_slots(unsigned hw) { const char* e = getenv("RT_HIP_REFILL_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : hw; }
-
 // n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
 template <class BoxT, int WIDTH, bool STATS, bool SHADE, int MODE>
-static void launch_walk_k(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
-                          HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries, uint32_t ovf_waves,
-                          hipStream_t s) {
+static void launch_walk_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min,
+                          double t_max, HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, uint32_t stack_entries,
+                          uint32_t ovf_waves, hipStream_t s) {
     const size_t lds = (size_t)stack_entries * TRACE_BLOCK * sizeof(uint32_t);
-    // the occupancy query is per (kernel instance, stack size); a handful of values occur
-    static unsigned cached_slots[5] = {0, 0, 0, 0, 0};
+    // the occupancy query is per (kernel instance, stack size); a scene runs one box format, width and mode, and a handful
+    // of stack sizes occur: the answers are kept with the scene (one device), filled under the device's mutex
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
     constexpr bool OVF = MODE == WALK_OVF;
     auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
-    if (!cached_slots[ci]) cached_slots[ci] = resident_waves(kernel, lds);
+    unsigned& cached = ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
+    if (!cached) cached = resident_waves(kernel, lds);
     const unsigned chunks = (n_upper + 63u) / 64u;
     // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks.
-    // The trace-and-shade kernel gets a share of the slots only (RT_HIP_TAIL_SLOTS): its queue is a few per cent of the pass,
-    // its waves hold twice the registers of the other kernels' and stay until their last path ends, so a full grid of them
-    // would shut the other passes in flight out of the SIMDs.
-    unsigned hw = cached_slots[ci];
+    unsigned hw = cached;
     // With an estimate of the queue's size (what the previous passes reported) the grid is sized for it — a wave per 64
     // expected entries, a quarter more for safety; the waves are persistent, so any real size is still served in full.
     if (n_estimate) hw = std::min<unsigned>(hw, std::max<unsigned>(64u, (n_estimate + n_estimate / 4 + 63u) / 64u));
-    if (SHADE) {
-        static const int ts = getenv("RT_HIP_TAIL_SLOTS") ? atoi(getenv("RT_HIP_TAIL_SLOTS")) : 0;
-        if (ts > 0) hw = (unsigned)ts;
-    }
-    unsigned slots = refill_enabled() ? std::min(refill_slots(hw), chunks) : chunks;
+    // (tests: one-chunk-per-wave launches instead of persistent ones, or a given number of persistent waves)
+    unsigned slots = ctx.refill ? std::min(ctx.refill_slots ? ctx.refill_slots : hw, chunks) : chunks;
     if (OVF) slots = std::min<unsigned>(slots, ovf_waves);      // the overflow rows have one column per launched lane
     if (!slots) return;
     hipLaunchKernelGGL(kernel, dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
 }
 template <class BoxT, int WIDTH>
-static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
+static void launch_walk_b(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
                           HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
                           hipStream_t s) {
     // The per-lane stack needs S.stack4 entries for the BVH4 and one entry per level for the BVH2; a smaller stack means
@@ -1247,17 +1174,17 @@ static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint
     auto go = [&](auto mode, uint32_t rows, uint32_t ovf_waves) {
         constexpr int M = decltype(mode)::value;
         if (sh) {
-            if (stats) launch_walk_k<BoxT, WIDTH, true, true, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
-            else launch_walk_k<BoxT, WIDTH, false, true, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            if (stats) launch_walk_k<BoxT, WIDTH, true, true, M>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            else launch_walk_k<BoxT, WIDTH, false, true, M>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
         } else {
-            if (stats) launch_walk_k<BoxT, WIDTH, true, false, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
-            else launch_walk_k<BoxT, WIDTH, false, false, M>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            if (stats) launch_walk_k<BoxT, WIDTH, true, false, M>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
+            else launch_walk_k<BoxT, WIDTH, false, false, M>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, rows, ovf_waves, s);
         }
     };
     if constexpr (WIDTH == 4) {
         // deep trees: 32 rows in LDS, the rest in the caller's overflow buffer (persistent launches only: a column per launched lane)
-        const uint32_t lds_rows = ovf_lds_rows();
-        if (need > lds_rows && ovf.rows && need <= lds_rows + ovf.rows_cap && ovf.waves && refill_enabled()) {
+        const uint32_t lds_rows = ctx.ovf_lds_rows;
+        if (need > lds_rows && ovf.rows && need <= lds_rows + ovf.rows_cap && ovf.waves && ctx.refill) {
             w.stack_ovf = ovf.rows;
             w.ovf_lds_rows = lds_rows;
             go(std::integral_constant<int, WALK_OVF>(), lds_rows, ovf.waves);
@@ -1270,34 +1197,32 @@ static void launch_walk_b(const DScene& S, RayQueue q, const QueueGeom& qg, uint
     }
     go(std::integral_constant<int, WALK_PLAIN>(), entries, 0u);
 }
-static void launch_walk_any(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
+static void launch_walk_any(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
                             HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
                             hipStream_t s) {
     if (!n_upper) return;
     if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
-        if (S.nodes4) { launch_walk_b<Box16, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
-        if (S.nodes4f) { launch_walk_b<Box32, 4>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
+        if (S.nodes4) { launch_walk_b<Box16, 4>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
+        if (S.nodes4f) { launch_walk_b<Box32, 4>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
     }
     if (S.nodes16)
-        launch_walk_b<Box16, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
+        launch_walk_b<Box16, 2>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
     else if (S.nodes32)
-        launch_walk_b<Box32, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
+        launch_walk_b<Box32, 2>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
     else
-        launch_walk_b<Box64, 2>(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
+        launch_walk_b<Box64, 2>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
 }
-uint32_t stack_overflow_rows(const DScene& S) {
-    const bool off = getenv("RT_HIP_NO_STACK_OVF") && atoi(getenv("RT_HIP_NO_STACK_OVF")) == 1;
+uint32_t stack_overflow_rows(const DScene& S, uint32_t lds_rows) {
     const bool w4 = S.stack4 <= (uint32_t)BVH4_MAX_STACK && (S.nodes4 || S.nodes4f);
-    const uint32_t lds_rows = ovf_lds_rows();
-    return (!off && w4 && S.stack4 > lds_rows) ? S.stack4 - lds_rows : 0u;
+    return (w4 && S.stack4 > lds_rows) ? S.stack4 - lds_rows : 0u;
 }
-void launch_walk(const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb, bool stats,
-                 unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {
+void launch_walk(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,
+                 bool stats, unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {
     StackOverflow none = {nullptr, 0u, 0u};
-    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, nullptr, ovf ? *ovf : none, s);
+    launch_walk_any(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, nullptr, ovf ? *ovf : none, s);
 }
-void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg, uint32_t n_upper,
-                       double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
+void launch_walk_shade(LaunchCtx& ctx, const DScene& S, const PassParams& pp, uint32_t depth0, RayQueue q, const QueueGeom& qg,
+                       uint32_t n_upper, double t_min, double t_max, HitBuf hb, double* d_path_radiance, uint32_t* d_hist, bool stats,
                        unsigned long long* d_counters, hipStream_t s, uint32_t n_estimate, const StackOverflow* ovf) {
     WalkShade sh;
     memset(&sh, 0, sizeof(sh));
@@ -1306,7 +1231,7 @@ void launch_walk_shade(const DScene& S, const PassParams& pp, uint32_t depth0, R
     sh.path_radiance = d_path_radiance;
     sh.hist = d_hist;
     StackOverflow none = {nullptr, 0u, 0u};
-    launch_walk_any(S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, &sh, ovf ? *ovf : none, s);
+    launch_walk_any(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, &sh, ovf ? *ovf : none, s);
 }
 
 bool packet_supported(const DScene& S) { return S.nodes32 != nullptr; }   // f64-box scenes have no packet variant
@@ -1367,6 +1292,14 @@ void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint
 void launch_resolve(const double* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
+}
+void launch_narrow_f32(const double* d_in, float* d_out, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_narrow_f32, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_in, d_out, n);
+}
+void launch_resolve_f32(const float* d_sum, double* d_mean, size_t n, double total_spp, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_resolve_f32, dim3(grid_for(n)), dim3(BLOCK), 0, s, d_sum, d_mean, n, total_spp);
 }
 void launch_gamma8(const double* d_mean, size_t n, uint8_t* d_out, hipStream_t s) {
     if (!n) return;

@@ -23,6 +23,7 @@ def hip():
         h.hipStreamSynchronize.argtypes = [C.c_void_p]
         h.hipSetDevice.argtypes = [C.c_int]
         h.hipGetDevice.argtypes = [C.POINTER(C.c_int)]
+        h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _hip = h
     return _hip
 
@@ -70,3 +71,10 @@ class DeviceBuffer:
 
 def synchronize():
     _ok(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+def free_bytes():
+    """hipMemGetInfo's free device memory on the current device."""
+    free, total = C.c_size_t(), C.c_size_t()
+    _ok(hip().hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value

@@ -110,6 +110,67 @@ def test_render_multi_one_device_equals_rt_render(mixed):
     assert L.rt_render_multi(handles, 0, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID
 
 
+def test_render_multi_f32_exchange_and_reuse_of_the_scene_buffers(mixed):
+    """RT_OPT_REDUCE_F32: the per-device sums cross the exchange as f32, everything before it is f64 — so
+    with one device the frame is rt_render's to f32 rounding of the per-pixel SUM.  The sum buffers and the stream
+    belong to the scene: a second call at another frame size (smaller, then larger) reuses / regrows them."""
+    desc, world = mixed
+    for w, h, spp in ((80, 60, 7), (48, 36, 5), (128, 96, 3)):
+        cam = scenes.cam1(w, h, max_depth=8)
+        ref = cam.render_image(world, spp=spp, seed=9)
+        img = cam.render_image_multi([world], spp=spp, seed=9, reduce_f32=True)
+        np.testing.assert_allclose(img, ref, rtol=2.0 ** -23, atol=1e-30)
+        assert not np.array_equal(img, ref)                              # it did go through f32
+        assert np.array_equal(cam.render_image_multi([world], spp=spp, seed=9), ref)
+    L = lib()
+    cam = scenes.cam1(80, 60, max_depth=8)
+    o = cam.opts(spp=7, seed=9)
+    o["flags"] = 0x80
+    out = np.zeros((60, 80, 3))
+    handles = (C.c_void_p * 1)(world._h)
+    assert L.rt_render_multi(handles, 1, _abi.ptr(cam.rec), _abi.ptr(o), _abi.ptr(out), None) == _abi.RT_ERR_INVALID
+
+
+def test_two_threads_render_two_scenes_while_a_third_traces(mixed, oracle):
+    """include/rt_hip.h promises handles that are shareable across threads and calls serialised per device — what the
+    reference's Arc<World> sharing between the render thread and the window thread needs (src/window.rs:48-49, :76-82).
+    Two host threads render two scenes on the one device and a third runs closest-hit batches on the first scene (the
+    allocation-free entry stays out: its scratch array is shared per device by contract): every result equals the
+    serial one bit for bit."""
+    import threading
+    desc, world = mixed
+    desc2 = scenes.mixed_test_scene(seed=5, n_spheres=30, quads=10)
+    world2 = World.build(desc2)
+    cam = scenes.cam1(128, 96, max_depth=12)
+    kw = dict(spp=8, seed=3, max_paths_in_flight=128 * 96 * 2)       # four passes, several pipes
+    k = np.arange(50_000)
+    rays = np.zeros(len(k), _abi.ray_dt)
+    rays["o"] = np.stack([-6.0 + 12.0 * scenes.hash_u01(91, k, c) for c in range(3)], -1)
+    rays["d"] = np.stack([2.0 * scenes.hash_u01(92, k, c) - 1.0 for c in range(3)], -1)
+    want = (cam.render_image(world, **kw), cam.render_image(world2, **kw), world.hit(rays))
+    got, errors = {}, []
+
+    def run(name, fn, rounds):
+        try:
+            for r in range(rounds):
+                got[(name, r)] = fn()
+        except Exception as e:                                        # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=run, args=("a", lambda: cam.render_image(world, **kw), 3)),
+               threading.Thread(target=run, args=("b", lambda: cam.render_image(world2, **kw), 3)),
+               threading.Thread(target=run, args=("c", lambda: world.hit(rays), 6))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for r in range(3):
+        assert np.array_equal(got[("a", r)], want[0]) and np.array_equal(got[("b", r)], want[1])
+    for r in range(6):
+        assert np.array_equal(got[("c", r)]["prim"], want[2]["prim"]) and np.array_equal(got[("c", r)]["t"], want[2]["t"])
+
+
 def test_streams_the_host_made_before_do_not_change_the_image(monkeypatch):
     """A render with several passes in flight puts its pipes on streams of the scene's own and checks once per scene that
     they sit on different hardware queues (ensure_pipe_streams); how many streams the host made before decides how many

@@ -52,6 +52,26 @@ def test_noalloc_entry_matches_rt_trace_closest_twice_in_a_row():
     assert np.array_equal(got["prim"], ref["prim"]) and np.array_equal(got["t"], ref["t"])
 
 
+def test_noalloc_entry_leaves_device_memory_as_it_is():
+    """The header promises no allocating call: free device memory (hipMemGetInfo) is the same before and after — also
+    for the FIRST call on a scene, whose kernels rt_scene_create has run once so that no code object is loaded and no
+    occupancy query is made here."""
+    from hip_mem import DeviceBuffer, free_bytes, synchronize
+    world = World.build(scenes.mixed_test_scene(seed=3, n_spheres=25, quads=9))      # a scene nothing has traced yet
+    rays = _rays(70_001, 35)
+    d_rays = DeviceBuffer.from_array(rays)
+    d_hits = DeviceBuffer(len(rays) * _abi.hit_dt.itemsize)
+    synchronize()
+    before = free_bytes()
+    for n in (len(rays), 1_000, len(rays)):
+        check(lib().rt_trace_closest_noalloc(world._h, d_rays.ptr, n, 0.001, 1e300, d_hits.ptr, None))
+        synchronize()
+        assert free_bytes() == before
+    got = d_hits.to_array(_abi.hit_dt, len(rays))
+    ref = world.hit(rays, 0.001, 1e300)
+    assert np.array_equal(got["prim"], ref["prim"]) and np.array_equal(got["t"], ref["t"])
+
+
 def test_noalloc_entry_limits_and_arguments():
     from hip_mem import DeviceBuffer
     world = World.build(scenes.mixed_test_scene())
