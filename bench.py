@@ -8,9 +8,11 @@ height-field mesh, 1 002 528 triangles, Lambertian/metal materials under the (pl
 1920x1080, 256 spp per GPU, max depth 50.  One "step" = one full render of that frame on every GPU:
 rank r renders the global sample indices r, r+N, r+2N, ... (scene replicated in each GPU's HBM), the
 per-GPU radiance-sum buffers are combined with one RCCL sum-reduce, rank 0 resolves the mean.  Work
-per GPU is fixed as N grows ("weak"): the frame gets 256*N spp in the same time.
+per GPU is fixed as N grows ("weak", the default): the frame gets 256*N spp in the same time.
+`--scaling strong` fixes the JOB instead (BASELINE config 4: "1080p @ 1024 spp, 1/2/4/8 GPUs"): the frame's spp are
+split over the ranks, ceil((spp - r) / N) for rank r, and the JSON line says "scaling": "strong".
 
-value = W*H*spp_per_gpu*N / t_step / 1e6 (Msamples/s, whole job), inputs resident in HBM.
+value = W*H*global_spp / t_step / 1e6 (Msamples/s, whole job), inputs resident in HBM.
 """
 import argparse
 import ctypes as C
@@ -33,7 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="heightfield_1m", choices=["heightfield_1m", "cover", "textured_5m", "large_20m"])
-    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (default: the config's)")
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel: per GPU (weak) or of the whole job (strong); default: the config's")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --spp per GPU, the job grows with N; strong: --spp for the whole job, split over the N ranks")
     ap.add_argument("--width", type=int, default=None, help="default 1920 (3840 for large_20m)")
     ap.add_argument("--height", type=int, default=None, help="default 1080 (2160 for large_20m)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,18 +132,43 @@ def pmc_traffic(workload):
     return walk("traffic_bytes_per_launch"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the launcher must stay free of a GPU context: its
+    children are the ranks): the KFD topology in sysfs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.
+    None when the topology cannot be read (the ranks then find out themselves)."""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for f in files:
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start N fresh rank processes of this same
     script, one per GPU, BEFORE anything in this process touches the GPU (a process that has initialised HIP must not
     exec, and a parent holding a HIP context would only be in the way), relay rank 0's JSON line, and exit with the
-    worst exit status.  Under `python -m torch.distributed.run` WORLD_SIZE is set and this is skipped."""
+    worst exit status.  All ranks are watched together: when one exits with an error the others — which would sit in
+    the rendezvous or in a collective until it times out — are terminated.  Under `python -m torch.distributed.run`
+    WORLD_SIZE is set and this is skipped."""
     import socket
     import subprocess
+    import threading
     n = args.gpus
     if not STANDIN:
-        import torch                                   # device_count() does not initialise the GPU on this image
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -149,12 +178,29 @@ def launch_ranks(args):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # ROCm's legacy IPC handles do not work in this driver stack (only dmabuf IPC does): without this RCCL's
+        # intra-node transport fails in hipIpcGetMemHandle.  The harness exports it already; kept for a bare shell.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode("utf-8", "replace")
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)      # rank 0's pipe must not fill up
+    reader.start()
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and not failed:
+                    failed = True
+                    for q in procs:                       # the siblings wait for a rank that is gone
+                        if q.poll() is None:
+                            q.terminate()
+        if any(rc is None for rc in rcs):
+            time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write((out0[0] if out0 else b"").decode("utf-8", "replace"))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -170,9 +216,11 @@ def standin_main(args, rank, world):
     import torch
     import torch.distributed as dist
     from rt_amd.distributed import render_distributed
+    if os.environ.get("RT_BENCH_STANDIN_FAIL_RANK") == str(rank):      # launcher test: a rank that dies before the rendezvous
+        raise SystemExit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_val, spp = 24, 5
+    n_val, spp = 24, args.spp or 5
 
     def sample_image(s):            # a deterministic "radiance" of global sample index s
         return torch.arange(n_val, dtype=torch.float64) * 0.25 + float(s * s % 7)
@@ -185,14 +233,16 @@ def standin_main(args, rank, world):
     out = torch.zeros(n_val, dtype=torch.float64)
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
-        mean, _ = render_distributed(render_sum, out, spp, seed=0)
+        mean, _ = render_distributed(render_sum, out, spp, seed=0, scaling=args.scaling)
     dt = time.perf_counter() - t0
     if rank == 0:
-        want = sum(sample_image(s) for s in range(spp * world)) / float(spp * world)
+        total = spp * world if args.scaling == "weak" else spp
+        want = sum(sample_image(s) for s in range(total)) / float(total)
         print(json.dumps({"metric": "launcher self-test (not a measurement)", "value": 0.0, "unit": "none", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "standin-selftest",
-                          "config": {"workload": "synthetic per-sample images over gloo", "partition": f"sample index mod {world}"},
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "standin-selftest",
+                          "config": {"workload": "synthetic per-sample images over gloo", "partition": f"sample index mod {world}",
+                                     "global_spp": total},
                           "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                           "standin_max_abs_err": float((mean - want).abs().max())}), flush=True)
     if world > 1:
@@ -273,7 +323,8 @@ def main():
         if exchanged[b] is not None:
             torch.cuda.current_stream().wait_event(exchanged[b])      # the frame before last has left this buffer
         mean, st = render_distributed(render_sum, sums[b], spp_override or spp, seed=2024,
-                                      resolve=lambda s, total: hip_resolve(s, total, local_rank), side_stream=side)
+                                      resolve=lambda s, total: hip_resolve(s, total, local_rank), side_stream=side,
+                                      scaling=args.scaling)
         if side is not None:
             exchanged[b] = torch.cuda.Event()
             exchanged[b].record(side)
@@ -285,7 +336,7 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    stats = [st_ for st_ in (step() for _ in range(args.steps)) if st_ is not None]      # (None: a rank beyond the sample count)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -298,7 +349,9 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        samples_per_step = W * H * spp * world
+        from rt_amd.distributed import partition
+        spp_rank0, _, _, global_spp = partition(spp, 0, world, args.scaling)
+        samples_per_step = W * H * global_spp
         value = samples_per_step / (dt / args.steps) / 1e6
         rays_per_s = float(seg.item()) / dt
         # ---- roofline of the dominant kernel: k_walk on the first-bounce queue (per-lane BVH traversal, one launch per
@@ -320,7 +373,7 @@ def main():
         if not args.no_alone:
             prev_pipes = os.environ.get("RT_HIP_PIPES")
             os.environ["RT_HIP_PIPES"] = "1"
-            ast = hip_render_sum(w._h, cam, spp, 0, 1, 2024, scratch, local_rank, False)
+            ast = hip_render_sum(w._h, cam, spp_rank0, 0, 1, 2024, scratch, local_rank, False)
             torch.cuda.synchronize()
             if prev_pipes is None:
                 del os.environ["RT_HIP_PIPES"]
@@ -358,10 +411,11 @@ def main():
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": label, "width": W, "height": H, "spp_per_gpu": spp, "global_spp": spp * world,
-                       "max_depth": cam.max_depth, "partition": f"sample index mod {world}", "n_prims": info["n_prims"]},
+            "config": {"workload": label, "width": W, "height": H, "spp_per_gpu": spp_rank0, "global_spp": global_spp,
+                       "max_depth": cam.max_depth, "partition": f"sample index mod {world}" + (", ceil((spp - r) / N) per rank" if args.scaling == "strong" else ""),
+                       "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
             "launches_per_step": S("launches") / args.steps, "passes_per_step": n_passes / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -24,17 +24,24 @@ __device__ __forceinline__ D3 scale(D3 a, double s) { return mk(a.x * s, a.y * s
 // q = RN(q0 + r*y).  With y within an ulp of 1/s, q0 + r*y is a/s to ~2^-104 relative, and a quotient of two doubles
 // is never that close to a rounding boundary without being exact, so q is the correctly rounded a / s — bit for bit
 // what three IEEE divisions give (it is the quotient step of the compiler's own division sequence; tests/native/
-// div_shared_check.c compares the two over 3e8 cases incl. significands of all ones).  20 instead of 33 f64
-// instructions per vector; a shaded vertex does three of these.  The form needs the remainder not to underflow and
-// y to be finite and non-zero: outside 2^-500 < |s| < 2^500 (never on the path: s is a vector length or a colour
-// component) the plain divisions are used; numerators below 2^-900 in magnitude other than 0 do not occur (directions
-// and colours), a zero numerator gives +0 where the division gives the numerator's sign.
+// div_shared_check.c compares the two over 3e8 cases incl. significands of all ones, zero numerators of either sign and
+// negative divisors).  20 instead of 33 f64 instructions per vector; a shaded vertex does three of these.  The form needs
+// the remainder not to underflow and y to be finite and non-zero: outside 2^-500 < |s| < 2^500 (never on the path: s is a
+// vector length or a colour component) the plain divisions are used; numerators are finite and, other than 0, not below
+// 2^-900 in magnitude (directions and colours).  A zero numerator would come out as +0 whatever its sign (the remainder
+// step adds zeros of opposite sign), so the quotient's sign is set to sign(a) ^ sign(s) explicitly — two integer
+// instructions per component — which is what the division gives for every operand pair.
+__device__ __forceinline__ double quot_sign(double q, double a, double s) {
+    const uint32_t sg = ((uint32_t)__double2hiint(a) ^ (uint32_t)__double2hiint(s)) & 0x80000000u;
+    return __hiloint2double((int)(((uint32_t)__double2hiint(q) & 0x7fffffffu) | sg), __double2loint(q));
+}
 __device__ __forceinline__ D3 divs(D3 a, double s) {
     const double m = fabs(s);
     if (!(m > 0x1.0p-500 && m < 0x1.0p500)) return mk(a.x / s, a.y / s, a.z / s);
     const double y = 1.0 / s;
     const double qx = a.x * y, qy = a.y * y, qz = a.z * y;
-    return mk(fma(fma(-s, qx, a.x), y, qx), fma(fma(-s, qy, a.y), y, qy), fma(fma(-s, qz, a.z), y, qz));
+    return mk(quot_sign(fma(fma(-s, qx, a.x), y, qx), a.x, s), quot_sign(fma(fma(-s, qy, a.y), y, qy), a.y, s),
+              quot_sign(fma(fma(-s, qz, a.z), y, qz), a.z, s));
 }
 __device__ __forceinline__ D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }

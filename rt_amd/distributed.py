@@ -16,9 +16,21 @@ import torch.distributed as dist
 from . import _abi
 
 
-def partition(spp_per_rank, rank, world):
-    """(spp, sample_offset, sample_stride) of this rank."""
-    return spp_per_rank, rank, world
+def partition(spp, rank, world, scaling="weak"):
+    """(samples of this rank, sample_offset, sample_stride, samples of the whole job).
+
+    Rank r always renders the global sample indices r, r + N, r + 2N, ... (offset = rank, stride = world), so the
+    union over the ranks is the sample set 0 .. total-1 of a single-GPU render of `total` samples.
+      weak   : `spp` samples PER RANK, the job renders spp * N  (work per GPU fixed as N grows);
+      strong : `spp` samples for the WHOLE JOB (BASELINE config 4: 1080p at 1024 spp on 1/2/4/8 GPUs): rank r takes
+               ceil((spp - r) / N) of them — the split rt_render_multi uses (rt_api.hip) — which may be uneven and is 0
+               for r >= spp."""
+    if scaling == "weak":
+        return spp, rank, world, spp * world
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'weak' or 'strong', not {scaling!r}")
+    mine = (spp - rank + world - 1) // world if spp > rank else 0
+    return mine, rank, world, spp
 
 
 def hip_render_sum(world_handle, cam, spp, sample_offset, sample_stride, seed, out_sum, device, collect_stats=False):
@@ -43,11 +55,12 @@ def hip_resolve(out_sum, total_spp, device):
     return mean
 
 
-def render_distributed(render_sum, out_sum, spp_per_rank, seed=0, resolve=None, side_stream=None):
+def render_distributed(render_sum, out_sum, spp, seed=0, resolve=None, side_stream=None, scaling="weak"):
     """Every rank calls this.  render_sum(spp, offset, stride, seed, out_sum) must ADD the rank's
     per-pixel sums into out_sum (a float64 tensor, zeroed here).  Returns (mean or None, stats):
     the mean image only on rank 0.  resolve(out_sum, total_spp) -> mean: the division on rank 0 (default: a torch
     division; GPU hosts pass hip_resolve so that the library's own resolve kernel runs).
+    spp / scaling: see partition() — per rank ("weak") or for the whole job ("strong").
 
     side_stream (GPU hosts rendering frame after frame): the exchange step — the sum-reduce and rank 0's resolve — is
     queued on that stream behind the render, so the next frame's kernels need not wait for the collective.  The caller
@@ -56,15 +69,15 @@ def render_distributed(render_sum, out_sum, spp_per_rank, seed=0, resolve=None, 
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     out_sum.zero_()
-    spp, off, stride = partition(spp_per_rank, rank, world)
-    stats = render_sum(spp, off, stride, seed, out_sum)
+    mine, off, stride, total = partition(spp, rank, world, scaling)
+    stats = render_sum(mine, off, stride, seed, out_sum) if mine > 0 else None      # (a rank beyond the sample count only joins the reduce)
 
     def exchange():
         if dist.is_initialized():
             dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
         if rank != 0:
             return None
-        return resolve(out_sum, spp_per_rank * world) if resolve else out_sum / float(spp_per_rank * world)
+        return resolve(out_sum, total) if resolve else out_sum / float(total)
 
     if side_stream is None:
         return exchange(), stats

@@ -53,3 +53,28 @@ def test_bench_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2
+
+
+def test_bench_strong_scaling_splits_a_fixed_job():
+    """--scaling strong: the job's spp are fixed and split over the ranks, ceil((spp - r) / N) for rank r — even (4 over
+    2), uneven (5 over 3: 2 + 2 + 1) and with a rank that gets nothing (2 over 3); the mean is that of the single-rank
+    job in every case (BASELINE config 4's 1/2/4/8-GPU runs; the split of rt_render_multi, src/camera.rs:316-324)."""
+    for n, spp in ((2, 4), (3, 5), (3, 2)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                            "--scaling", "strong", "--spp", str(spp)], env=_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _json_line(r.stdout)
+        assert d["scaling"] == "strong" and d["n_gpus"] == n and d["rccl_world_size"] == n
+        assert d["config"]["global_spp"] == spp and d["standin_max_abs_err"] < 1e-12
+
+
+def test_bench_launcher_ends_the_other_ranks_when_one_fails():
+    """A rank that dies before the rendezvous leaves the others waiting for it: the launcher terminates them and exits
+    non-zero instead of sitting out the collective's timeout."""
+    import time
+    env = dict(_env(), RT_BENCH_STANDIN_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
+    assert time.time() - t0 < 120

@@ -73,3 +73,23 @@ def test_single_process_path_needs_no_process_group():
 
     mean, st = render_distributed(render_sum, torch.zeros(6, dtype=torch.float64), 5)
     assert st == "stats" and torch.equal(mean, torch.full((6,), 2.0, dtype=torch.float64))
+
+
+def test_partition_weak_and_strong_cover_the_sample_set_exactly_once():
+    """partition(): in both modes the ranks' index sets r, r+N, ... are disjoint and their union is 0 .. total-1 — the
+    sample set of the single-GPU render the multi-GPU image must equal (src/camera.rs:316-324)."""
+    from rt_amd.distributed import partition
+    for scaling in ("weak", "strong"):
+        for world in (1, 2, 3, 4, 8):
+            for spp in (1, 2, 5, 8, 256, 1023, 1024):
+                seen = []
+                total_ = None
+                for r in range(world):
+                    mine, off, stride, total = partition(spp, r, world, scaling)
+                    total_ = total
+                    seen += [off + k * stride for k in range(mine)]
+                assert total_ == (spp * world if scaling == "weak" else spp)
+                assert sorted(seen) == list(range(total_)), (scaling, world, spp)
+    import pytest
+    with pytest.raises(ValueError):
+        partition(4, 0, 2, "sideways")

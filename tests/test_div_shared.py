@@ -12,4 +12,5 @@ def test_shared_reciprocal_division_is_exact(tmp_path):
                    check=True)
     r = subprocess.run([exe, "20000000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
-    assert "0 mismatches" in r.stdout
+    assert ", 0 mismatches" in r.stdout
+    assert ", 0 other differences" in r.stdout          # the sign of a zero quotient is the only thing the sign step changes

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -62,6 +63,17 @@ int main(int argc, char** argv) {
     const int cus = pr.multiProcessorCount; const double clk = pr.clockRate * 1e3;
     printf("%s: %d CUs, %.0f MHz\n", pr.name, cus, clk / 1e6);
     const size_t MiB = 1048576;
+    if (argc > 3 && std::string(argv[1]) == "calib") {
+        // calibration of the FETCH_SIZE counter for random gathers (tools/calib_fetch.sh): ONE configuration, run under
+        // rocprofv3 --pmc; prints the number of lane fetches of all its launches (1 warm-up + 4 timed) so that the counter
+        // can be set against known bytes: lane fetches x bytes per fetch x (L2 miss share, from TCC_MISS / TCC_REQ)
+        const int bytes = atoi(argv[2]);
+        const size_t tb = (size_t)atoi(argv[3]) * MiB;
+        if (bytes == 32) run<32>(tb, 16, 64, cus, clk); else if (bytes == 64) run<64>(tb, 16, 64, cus, clk); else run<128>(tb, 16, 64, cus, clk);
+        printf("calib: bytes_per_fetch %d table_mib %zu lane_fetches_all_launches %.0f\n", bytes == 32 || bytes == 64 ? bytes : 128, tb / MiB,
+               5.0 * cus * 16 * 64 * 512);
+        return 0;
+    }
     if (argc > 1) {      // sweep of the table size: where the fetch rate falls off the per-XCD L2 (4 MiB) and the Infinity Cache
         for (size_t mb : {1, 2, 4, 8, 16, 32, 64, 256}) {
             run<32>(mb * MiB, 16, 64, cus, clk); run<64>(mb * MiB, 16, 64, cus, clk); run<128>(mb * MiB, 16, 64, cus, clk);
