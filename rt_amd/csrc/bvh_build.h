@@ -52,4 +52,22 @@ bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vect
 // the same with f32 boxes rounded outward (no grid needed; the caller has checked that coordinates fit f32)
 bool widen_nodes_f32(const std::vector<Node64>& in, std::vector<Node4f>& out, uint32_t& stack_need);
 
+// BVH8 over the same leaves (rt_layout.h: Node8): every node absorbs the grandchildren with the largest boxes until it
+// has eight children; slots by octant order; boxes on the node's own 8-bit grid, rounded outward and checked exactly.
+// The result is the layout of the walk's record pool: record 0 is the root node, a node's internal children and then
+// its leaf primitives sit in one block, blocks in depth-first order.
+//   node_rec / nodes : nodes[i] belongs at record node_rec[i]
+//   tri_rec[k] / sph_rec[k] : record of the k-th triangle / sphere in the BVH2's leaf order (a leaf's primitives stay in a row)
+//   n_records : records of the pool; depth : levels of internal nodes (the walk's stack need)
+// Returns false when a box cannot be represented (coordinates beyond the exponent range) or the tree is deeper than
+// BVH8_MAX_DEPTH: the caller then walks another format.
+struct Wide8 {
+    std::vector<Node8> nodes;
+    std::vector<uint32_t> node_rec;
+    std::vector<uint32_t> tri_rec, sph_rec;
+    size_t n_records = 0;
+    uint32_t depth = 0;
+};
+bool widen_nodes8(const std::vector<Node64>& in, size_t n_triangles, size_t n_spheres, Wide8& out);
+
 }  // namespace rt

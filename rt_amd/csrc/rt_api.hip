@@ -93,6 +93,7 @@ struct Tuning {
     std::string builder;          // RT_HIP_BUILDER=lbvh: the device builder (tests/test_gpu_parity.py: both builders, same hits)
     std::string node_boxes;       // RT_HIP_NODE_BOXES=f64|f32|q16|w4|w4f|w8: force a node format (test_gpu_parity.py: every format)
     int all_lanes_load = -1;      // RT_HIP_ALL_LANES_LOAD=0|1: every-lane-fetches walk off / on (default: by scene size)
+    int bvh8 = -1;                // RT_HIP_BVH8=0|1: the BVH8 as the default format of the per-lane walk off / on (default: by scene size)
     // per call
     bool no_packet = false;       // RT_HIP_NO_PACKET: camera rays through the per-lane walk (test_gpu_configs.py: kernel variants)
     bool no_fuse = false;         // RT_HIP_NO_FUSE: depth-0 shading in k_shade instead of the camera-ray kernel
@@ -117,6 +118,7 @@ Tuning read_tuning() {
     t.builder = str("RT_HIP_BUILDER");
     t.node_boxes = str("RT_HIP_NODE_BOXES");
     t.all_lanes_load = set("RT_HIP_ALL_LANES_LOAD") ? (num("RT_HIP_ALL_LANES_LOAD", 0) != 0 ? 1 : 0) : -1;
+    t.bvh8 = set("RT_HIP_BVH8") ? (num("RT_HIP_BVH8", 0) != 0 ? 1 : 0) : -1;
     t.no_packet = set("RT_HIP_NO_PACKET");
     t.no_fuse = set("RT_HIP_NO_FUSE");
     t.primary_packet = set("RT_HIP_PRIMARY_PACKET");
@@ -324,6 +326,12 @@ void sphere_texture_rotation(const double f[3], double r[9]) {
     euler_matrix(0.0, 0.0, -yaw, b);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+// Scenes that walk the BVH8 by default (RT_HIP_NODE_BOXES=w8 / w4 / ... overrides either way)
+bool default_bvh8(size_t n_prims) {
+    (void)n_prims;
+    return false;
 }
 
 bool finite3(const double* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
@@ -992,7 +1000,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                     tg[k].e2[c] = t.c[c] - t.a[c];           // a_to_c (:413)
                 }
                 tg[k].prim = (uint32_t)(n_spheres + bvh.tri_order[k]);
-                tg[k]._pad = 0;
+                tg[k].kind = PRIM_KIND_TRIANGLE;
             }
             for (size_t i = i0; i < i1; ++i) {
                 const rt_triangle& t = triangles[i];
@@ -1026,7 +1034,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             }
             sg[k].r = spheres[i].radius;
             sg[k].prim = i;
-            sg[k]._pad = 0;
+            for (uint32_t& w : sg[k]._pad) w = 0;
+            sg[k].kind = PRIM_KIND_SPHERE;
         }
         const double tb1 = now_s();
 
@@ -1057,6 +1066,55 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                                           nd.right == REF_EMPTY ? 0.0 : std::max(std::fabs(nd.lo_r[k]), std::fabs(nd.hi_r[k])));
                 if (!(m < 1e30)) use32 = false;
             }
+        // ---- BVH8 (Node8): the per-lane walk's format when asked for (RT_HIP_NODE_BOXES=w8) or by default (below).  Its
+        // record pool holds the nodes AND the primitives, in the order of its own layout; the BVH2 arrays (camera rays)
+        // share the primitives, so their leaf references are re-expressed as pool records first.
+        sc->d.pool8 = nullptr;
+        sc->d.depth8 = 0;
+        bool use8 = false;
+        size_t n_nodes8 = 0;
+        if (use32 && n_prims && (nb == "w8" || (nb.empty() && (sc->tune.bvh8 >= 0 ? sc->tune.bvh8 != 0 : default_bvh8(n_prims))))) {
+            Wide8 w8;
+            if (widen_nodes8(bvh.nodes, n_triangles, n_spheres, w8)) {
+                static_assert(sizeof(Node8) == PRIM_RECORD_BYTES && sizeof(TriGeom) == PRIM_RECORD_BYTES && sizeof(SphGeom) == PRIM_RECORD_BYTES,
+                              "one stride for every record of the BVH8 pool");
+                std::vector<Node8> pool8(w8.n_records);
+                constexpr size_t NODE_PIECE8 = 16384;
+                for_each_piece((w8.nodes.size() + NODE_PIECE8 - 1) / NODE_PIECE8, [&](size_t piece) {
+                    for (size_t i = piece * NODE_PIECE8; i < std::min(w8.nodes.size(), (piece + 1) * NODE_PIECE8); ++i) pool8[w8.node_rec[i]] = w8.nodes[i];
+                });
+                for_each_piece(tri_pieces, [&](size_t piece) {
+                    size_t i0, i1;
+                    tri_piece(piece, i0, i1);
+                    for (size_t k = i0; k < i1; ++k) memcpy(&pool8[w8.tri_rec[k]], &tg[k], sizeof(TriGeom));
+                });
+                for (size_t k = 0; k < n_spheres; ++k) memcpy(&pool8[w8.sph_rec[k]], &sg[k], sizeof(SphGeom));
+                // BVH2 leaf references: `first` = the pool record of the leaf's first primitive (the rest follow it)
+                constexpr size_t N2_PIECE = 32768;
+                for_each_piece((bvh.nodes.size() + N2_PIECE - 1) / N2_PIECE, [&](size_t piece) {
+                    auto fix = [&](uint32_t ref) -> uint32_t {
+                        if (ref == REF_EMPTY || !(ref & REF_LEAF)) return ref;
+                        const uint32_t first = ref & REF_FIRST_MASK;
+                        return (ref & ~REF_FIRST_MASK) | ((ref & REF_SPHERE) ? w8.sph_rec[first] : w8.tri_rec[first]);
+                    };
+                    for (size_t i = piece * N2_PIECE; i < std::min(bvh.nodes.size(), (piece + 1) * N2_PIECE); ++i) {
+                        bvh.nodes[i].left = fix(bvh.nodes[i].left);
+                        bvh.nodes[i].right = fix(bvh.nodes[i].right);
+                    }
+                });
+                const Node8* pool_d = nullptr;
+                if ((rc = upload(sc, pool8, &pool_d))) return rc;
+                sc->d.pool8 = reinterpret_cast<const char*>(pool_d);
+                sc->d.depth8 = w8.depth;
+                sc->d.tris = reinterpret_cast<const TriGeom*>(pool_d);
+                sc->d.sphs = reinterpret_cast<const SphGeom*>(pool_d);
+                n_nodes8 = w8.nodes.size();
+                use8 = true;
+                if (sc->tune.debug) fprintf(stderr, "[rt_hip] BVH8: %zu nodes from %zu BVH2 nodes, %zu records, %u levels\n", n_nodes8, bvh.nodes.size(), w8.n_records, w8.depth);
+            } else if (sc->tune.debug) {
+                fprintf(stderr, "[rt_hip] BVH8: not representable for this scene, falling back\n");
+            }
+        }
         sc->d.nodes64 = nullptr;
         sc->d.nodes32 = nullptr;
         sc->d.nodes16 = nullptr;
@@ -1077,7 +1135,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             std::vector<Node16> n16;
             const bool force4 = nb == "w4";
             const bool force16 = nb == "q16" || force4, no16 = nb == "f32";
-            if (!no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
+            if (!use8 && !no16 && quantize_nodes(n32, n16, sc->d.grid, force16 ? 1e300 : 1.25)) {
                 for (int k = 0; k < 3; ++k) sc->d.grid_inv_cell[k] = 1.0 / (double)sc->d.grid.cell[k];
                 if ((rc = upload(sc, n16, &sc->d.nodes16))) return rc;
                 use16 = true;
@@ -1094,7 +1152,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             }
             // no usable grid: the BVH4 with f32 boxes (RT_HIP_NODE_BOXES=f32 keeps the BVH2 for A/B, =w4f forces this one)
             const bool force4f = nb == "w4f";
-            if ((!use16 && !no16) || force4f) {
+            if (!use8 && ((!use16 && !no16) || force4f)) {
                 uint32_t need = 0;
                 if (widen_nodes_f32(bvh.nodes, n4f, need) && need <= (uint32_t)BVH4_MAX_STACK) {
                     sc->d.stack4 = need;
@@ -1158,7 +1216,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
                 sc->d.sphs = reinterpret_cast<const SphGeom*>(pool_d + sph_off);
             }
         }
-        if (!sc->d.pool4) {
+        if (!sc->d.pool4 && !use8) {
             if ((rc = upload(sc, tg, &sc->d.tris))) return rc;
             if ((rc = upload(sc, sg, &sc->d.sphs))) return rc;
         }
@@ -1199,8 +1257,9 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         sc->info.n_nodes = bvh.nodes.size();
         sc->info.bvh_depth = bvh.depth;
         sc->info.max_leaf_size = bvh.max_leaf;
-        sc->info.node_bytes = use4f ? sizeof(Node4f) : use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
-        sc->info.bvh_width = use4 ? 4 : 2;
+        sc->info.node_bytes = use8 ? sizeof(Node8) : use4f ? sizeof(Node4f) : use4 ? sizeof(Node4) : use16 ? sizeof(Node16) : (use32 ? sizeof(Node32) : sizeof(Node64));
+        sc->info.bvh_width = use8 ? 8 : use4 ? 4 : 2;
+        (void)n_nodes8;
         sc->info.builder = sc->device_built ? 1u : 0u;
         (void)n_nodes4;
         sc->info.tri_bytes = sizeof(TriGeom);

@@ -598,6 +598,256 @@ __global__ RT_TAIL_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_wa
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1w — per-lane traversal of the BVH8 (rt_layout.h: Node8): an alternative to the BVH4 walk (RT_HIP_NODE_BOXES=w8).
+// ---------------------------------------------------------------------------------------------
+// Ray-side state.  A plane of a child box is the real number  origin_k + q * 2^e_k  (q = 0..255), so its ray parameter is
+//     t = (origin_k + q 2^e_k - o_k) / d_k = q * (2^e_k / d_k) + (origin_k - o_k) / d_k.
+// Per ray (Box32::set_axis):  idf = fl32(1/d),  K = fl32(o * idf),  c = |K| 2^-21,  KN = fl32(-K - c),  KF = fl32(-K + c).
+// Per node and axis:          adj = idf * 2^e (exact: a power of two),  s = |adj| 2^-15,
+//                             BN = fl32(fl32(origin * idf + KN) - s),   BF = fl32(fl32(origin * idf + KF) + s)   (two fma each)
+// Per plane:                  Y = fl32(q * adj + BN)  for near planes,  fl32(q * adj + BF)  for far planes        (one fma)
+// Error budget against the exact t, u = 2^-24:  q * adj + origin * idf = (origin + q 2^e) * idf exactly, and
+//     (origin + q 2^e) * idf - K = (1 + e2)[t - A e3],  A = o / d,  |e2|, |e3| <= u                 (Box32's budget: roundings of idf and K)
+// The roundings on top are KN's (<= u (|K| + c)), BN's two (each <= u |BN|, |BN| <= |Y| + 255 |adj| + s) and Y's (<= u |Y|):
+//     t - Y >= -(4.2 u) |Y| + (c - 3.2 u |K|) + (s - 2.1 u 255 |adj|)  >=  -2^-22 |Y|       since c = 8 u |K| and s = 512 u |adj|
+// and symmetrically for far planes: after  Y -> Y -/+ |Y| 2^-22  (applied once, after max3 / min3: it is monotone) a near
+// value is never above, a far value never below the exact one.  NaNs (0 * inf, inf - inf: rays parallel to a slab, products
+// beyond the f32 range) drop out of fmaxf / fminf or reach the negated comparisons, which accept; an infinity that survives has
+// the sign of the exact value (every term that can overflow carries the sign of its exact counterpart, and two terms of
+// opposite sign that both overflow give NaN).  The test only culls: primitives are intersected in f64 as in the other walks.
+struct Box8 : Box32 {
+    uint32_t oinv;     // bit k set: the ray runs in + direction on axis k (= 7 - octant)
+    uint32_t psel;     // v_perm_b32 selector moving byte j to byte j ^ (oinv >> 1): the byte part of the priority permutation
+    __device__ __forceinline__ void init(const DScene& S, D3 o, D3 d, double t_min, double t_max) {
+        Box32::init(S, o, d, t_min, t_max);
+        oinv = (ix < 0.f ? 0u : 1u) | (iy < 0.f ? 0u : 2u) | (iz < 0.f ? 0u : 4u);
+        psel = 0x03020100u ^ ((oinv >> 1) * 0x01010101u);
+    }
+    // nibble s -> nibble s ^ oinv: slot order to priority order (the highest nibble is the child to visit first)
+    __device__ __forceinline__ uint32_t to_priority(uint32_t x) const {
+        const uint32_t sw = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+        x = (oinv & 1u) ? sw : x;
+        return __builtin_amdgcn_perm(x, x, psel);
+    }
+};
+constexpr uint32_t G_HITS = 0x88888888u;      // pending children of a node group: top bit of the nibble at priority p
+constexpr uint32_t G_IMASK = 0x11111111u;     // internal-child slots of the group's node: low bit of the nibble at slot s
+
+// One step = one dependent memory round trip per lane, as in walk_body: a lane fetches ONE 80-byte record — the next
+// node of its pending group, or the next primitive of the node it tested last.  Per-lane state: the group (base =
+// first record of the node's block, g = pending internal children by priority + the node's internal-slot mask) and the
+// node's pending primitives (tb = hit bits by slot nibble, tp = the node's pmask, for the rank of a bit among the
+// records).  The stack holds groups only (two words each), at most one per level of internal nodes: S.depth8 entries.
+// A node's primitives are tested before its children are entered; children are entered in octant order.  Lane refill,
+// retiring, shading (SHADE) and the statistics are those of walk_body.
+template <bool STATS, bool SHADE>
+__device__ __forceinline__ void walk8_body(const DScene S, const RayQueue q, const QueueGeom qg, double t_min, double t_max,
+                                           const HitBuf hb, unsigned long long* counters, const WalkShade sh) {
+    extern __shared__ uint32_t stack_mem[];
+    uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
+    const uint32_t tid = threadIdx.x;
+    WaveQueue wq;
+    wq.load(qg, tid);
+    if (blockIdx.x == 0) {
+        uint32_t tot = wq.direct ? 0u : wq.cnt;
+        for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+        if (wq.direct) tot = wq.n_direct;
+        if (tid == 0) {
+            if (SHADE && sh.hist) *sh.hist = tot;
+            if (!wq.direct) const_cast<uint32_t*>(qg.count)[QUEUE_NWAVES_WORD] = wq.n_waves;
+            if (!SHADE && counters && tot) atomicAdd(&counters[STAT_SEGMENTS], (unsigned long long)tot);
+        }
+    }
+    wq.cnt = 0;
+    const uint32_t n_chunks = wq.n_waves, stride = gridDim.x;
+    uint32_t next_chunk = blockIdx.x, chunk = 0, chunk_pos = 64;      // wave-uniform
+    bool busy = false;
+    uint32_t slot = 0;
+    D3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+    D3 thr = mk(1, 1, 1);
+    uint32_t pid = 0, depth = 0;
+    Box8 rb;
+    rb.init(S, o, d, t_min, t_max);
+    double best = t_max;
+    uint32_t prim = RT_MISS;
+    uint32_t gbase = 0, g = 0, tb = 0, tp = 0;
+    int sp = 0;
+    uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_seg = 0;
+    // a ray starts with the root (record 0) as the only child of a virtual group: slot 0, pending at priority 0 ^ oinv
+#define RT_START_RAY() { gbase = 0u; g = S.root == REF_EMPTY ? 0u : ((0x8u << (4u * rb.oinv)) | 0x1u); tb = 0u; tp = 0u; sp = 0; best = t_max; prim = RT_MISS; }
+
+    for (;;) {
+        const bool at_prim = tb != 0u;
+        const bool at_node = !at_prim && (g & G_HITS) != 0u;
+        const unsigned long long m_live = __ballot(at_prim || at_node);
+        bool more = chunk_pos < 64u || next_chunk < n_chunks;
+        auto shade_service = [&]() -> bool {
+            const int n_fin = __popcll(__ballot(busy && !at_prim && !at_node));
+            const int n_idle = more ? __popcll(__ballot(!busy)) : 0;
+            return !m_live || n_fin + n_idle >= RT_REFILL_T;
+        };
+        if (SHADE ? shade_service() : (!m_live || (more && __popcll(m_live) <= 64 - RT_REFILL_T))) {
+            if (busy && !at_prim && !at_node) {                       // retire
+                if (SHADE) {
+                    ++n_seg;
+                    D3 no = mk(0, 0, 0), nd = mk(0, 0, 0), nthr = mk(0, 0, 0);
+                    const PathIndex ix = decode_path(sh.pp, pid);
+                    const bool alive = shade_path(S, sh.pp, depth, pid, ix.pixel, ix.local, slot, o, d, thr, prim, best, hb, sh.path_radiance, no, nd, nthr);
+                    if (alive) {
+                        o = no; d = nd; thr = nthr; ++depth;
+                        rb.init(S, o, d, t_min, t_max);
+                        RT_START_RAY()
+                    } else {
+                        busy = false;
+                    }
+                } else {
+                    hb.t[slot] = prim == RT_MISS ? 0.0 : best;
+                    hb.prim[slot] = prim;
+                    busy = false;
+                }
+            }
+            while (more) {                                            // refill
+                const unsigned long long m_idle = __ballot(!busy);
+                if (!m_idle) break;
+                if (chunk_pos >= 64u) {
+                    chunk = next_chunk; next_chunk += stride; chunk_pos = 0;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                const uint32_t take = min((uint32_t)__popcll(m_idle), 64u - chunk_pos);
+                uint32_t i = 0;
+                if (!busy && rank < take && wq.slot_light(qg, chunk, chunk_pos + rank, i)) {
+                    slot = i; busy = true;
+                    o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+                    d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+                    if (SHADE) {
+                        thr = mk(q.thr[0][i], q.thr[1][i], q.thr[2][i]);
+                        pid = q.pid[i];
+                        depth = sh.depth0;
+                    }
+                    rb.init(S, o, d, t_min, t_max);
+                    RT_START_RAY()
+                }
+                chunk_pos += take;
+                more = chunk_pos < 64u || next_chunk < n_chunks;
+            }
+            if (!__ballot(busy)) break;
+            continue;
+        }
+        if (STATS) ++n_iters;
+        // ---- which record: the next pending primitive of the node tested last, else the next pending child
+        uint32_t rec = 0;
+        if (at_prim) {
+            const uint32_t below = ~tb & (tb - 1u);                               // the bits below the lowest pending one
+            rec = gbase + (uint32_t)__popc(g & G_IMASK) + (uint32_t)__popc(tp & below);      // behind the internal children, by rank
+            tb &= tb - 1u;
+        } else if (at_node) {
+            const uint32_t b = 31u - (uint32_t)__clz((int)(g & G_HITS));          // highest pending priority
+            g &= ~(1u << b);
+            const uint32_t s_ = (b >> 2) ^ rb.oinv;                               // its slot
+            rec = gbase + (uint32_t)__popc(g & G_IMASK & ((1u << (4u * s_)) - 1u));
+            if (g & G_HITS) {                                                     // the rest of the group waits on the stack
+                stack[2 * sp][tid] = gbase;
+                stack[2 * sp + 1][tid] = g;
+                ++sp;
+            }
+        }
+        const uint4* p = reinterpret_cast<const uint4*>(S.pool8 + (uint64_t)rec * PRIM_RECORD_BYTES);
+        uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, r = a, e = a;
+        if (at_prim || at_node) { a = p[0]; b = p[1]; c = p[2]; r = p[3]; e = p[4]; }
+        if (at_node) {
+            if (STATS) ++n_nodes;
+            // Node8: a = origin, ex | b = base, inib, pmask | c = qlo_x, qlo_y | r = qlo_z, qhi_x | e = qhi_y, qhi_z (8 bytes each)
+            const float adjx = rb.ix * __uint_as_float((a.w & 0xFFu) << 23);
+            const float adjy = rb.iy * __uint_as_float(((a.w >> 8) & 0xFFu) << 23);
+            const float adjz = rb.iz * __uint_as_float(((a.w >> 16) & 0xFFu) << 23);
+            const float s15 = 0x1.0p-15f, r22 = 0x1.0p-22f;
+            const float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+            const float bnx = fmaf(-fabsf(adjx), s15, fmaf(ox, rb.ix, rb.nx)), bfx = fmaf(fabsf(adjx), s15, fmaf(ox, rb.ix, rb.fx));
+            const float bny = fmaf(-fabsf(adjy), s15, fmaf(oy, rb.iy, rb.ny)), bfy = fmaf(fabsf(adjy), s15, fmaf(oy, rb.iy, rb.fy));
+            const float bnz = fmaf(-fabsf(adjz), s15, fmaf(oz, rb.iz, rb.nz)), bfz = fmaf(fabsf(adjz), s15, fmaf(oz, rb.iz, rb.fz));
+            // near and far planes of each axis by the sign of the direction: whole words, eight children at a time
+            const bool ngx = rb.ix < 0.f, ngy = rb.iy < 0.f, ngz = rb.iz < 0.f;
+            const uint32_t nxw[2] = {ngx ? r.z : c.x, ngx ? r.w : c.y}, fxw[2] = {ngx ? c.x : r.z, ngx ? c.y : r.w};
+            const uint32_t nyw[2] = {ngy ? e.x : c.z, ngy ? e.y : c.w}, fyw[2] = {ngy ? c.z : e.x, ngy ? c.w : e.y};
+            const uint32_t nzw[2] = {ngz ? e.z : r.x, ngz ? e.w : r.y}, fzw[2] = {ngz ? r.x : e.z, ngz ? r.y : e.w};
+            uint32_t hitnib = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int w = k >> 2, shf = 8 * (k & 3);
+                const float qnx = (float)((nxw[w] >> shf) & 0xFFu), qfx = (float)((fxw[w] >> shf) & 0xFFu);
+                const float qny = (float)((nyw[w] >> shf) & 0xFFu), qfy = (float)((fyw[w] >> shf) & 0xFFu);
+                const float qnz = (float)((nzw[w] >> shf) & 0xFFu), qfz = (float)((fzw[w] >> shf) & 0xFFu);
+                float tn = fmaxf(fmaxf(fmaf(qnx, adjx, bnx), fmaf(qny, adjy, bny)), fmaf(qnz, adjz, bnz));
+                float tf = fminf(fminf(fmaf(qfx, adjx, bfx), fmaf(qfy, adjy, bfy)), fmaf(qfz, adjz, bfz));
+                tn = fmaf(-fabsf(tn), r22, tn);
+                tf = fmaf(fabsf(tf), r22, tf);
+                const bool h = !(tn > tf) && !(tf < rb.lo_t) && !(tn > rb.hi_t);
+                hitnib |= h ? (0xFu << (4 * k)) : 0u;
+            }
+            // (an empty slot has neither an inib nor a pmask nibble: whatever its test said, it drops out here)
+            gbase = b.x;
+            g = (rb.to_priority(hitnib & b.y) & G_HITS) | (b.y & G_IMASK);
+            tb = hitnib & b.z;
+            tp = b.z;
+        }
+        if (at_prim) {
+            if (STATS) ++n_prims;
+            if (e.w == (uint32_t)PRIM_KIND_TRIANGLE) {                // TriGeom: a, e1, e2 (9 doubles), prim, kind
+                const D3 ta = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
+                const D3 e1 = mk(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
+                const D3 e2 = mk(mkd(r.x, r.y), mkd(r.z, r.w), mkd(e.x, e.y));
+                double t, u, v;
+                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) {
+                    best = t; prim = e.z; rb.nearest(best);
+                    hb.bu[slot] = u; hb.bv[slot] = v;
+                }
+            } else {                                                  // SphGeom: c, r, rot2 (7 doubles), prim
+                const D3 sc = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
+                const double sr = mkd(b.z, b.w);
+                const D3 rot2 = mk(mkd(c.x, c.y), mkd(c.z, c.w), mkd(r.x, r.y));
+                double t;
+                if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
+            }
+        }
+        // nothing pending at this node any more: back to the group that was set aside last
+        if ((at_prim || at_node) && tb == 0u && !(g & G_HITS) && sp) {
+            --sp;
+            gbase = stack[2 * sp][tid];
+            g = stack[2 * sp + 1][tid];
+        }
+    }
+#undef RT_START_RAY
+    if (SHADE && counters) {
+        unsigned long long sg = n_seg;
+        for (int off = 32; off; off >>= 1) sg += __shfl_xor(sg, off);
+        if (tid == 0 && sg) atomicAdd(&counters[STAT_SEGMENTS], sg);
+    }
+    if (STATS) {
+        unsigned long long a = n_nodes, b = n_prims;
+        for (int off = 32; off; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+        }
+        if (tid == 0) {
+            atomicAdd(&counters[STAT_NODES], a);
+            atomicAdd(&counters[STAT_PRIMS], b);
+            atomicAdd(&counters[STAT_ITERS], (unsigned long long)n_iters);
+            atomicAdd(&counters[STAT_LEAVES], b);
+        }
+    }
+}
+template <bool STATS>
+__global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk8(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max, HitBuf hb,
+                                                                      unsigned long long* counters, WalkShade sh) {
+    walk8_body<STATS, false>(S, q, qg, t_min, t_max, hb, counters, sh);
+}
+template <bool STATS>
+__global__ RT_TAIL_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk8_shade(DScene S, RayQueue q, QueueGeom qg, double t_min, double t_max,
+                                                                                      HitBuf hb, unsigned long long* counters, WalkShade sh) {
+    walk8_body<STATS, true>(S, q, qg, t_min, t_max, hb, counters, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1p — closest hit for COHERENT waves (camera rays of an 8x8 pixel tile): packet traversal.
 // The wave walks the BVH once: the current node, the stack and the loop are wave-uniform, nodes
 // and primitives are fetched through the SCALAR cache (one s_load per node for all 64 rays instead
@@ -1197,10 +1447,41 @@ static void launch_walk_b(LaunchCtx& ctx, const DScene& S, RayQueue q, const Que
     }
     go(std::integral_constant<int, WALK_PLAIN>(), entries, 0u);
 }
+// the BVH8 walk: the whole stack in LDS (two words per level of internal nodes)
+template <bool STATS, bool SHADE>
+static void launch_walk8_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min,
+                           double t_max, HitBuf hb, unsigned long long* d_counters, const WalkShade& sh, hipStream_t s) {
+    const uint32_t need = std::max(S.depth8, 1u);
+    const uint32_t entries = need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : (uint32_t)BVH8_MAX_DEPTH;
+    const int ci = entries <= 8 ? 0 : entries <= 12 ? 1 : entries <= 16 ? 2 : 3;
+    const size_t lds = (size_t)2 * entries * TRACE_BLOCK * sizeof(uint32_t);
+    auto kernel = [] { if constexpr (SHADE) return k_walk8_shade<STATS>; else return k_walk8<STATS>; }();
+    unsigned& cached = ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
+    if (!cached) cached = resident_waves(kernel, lds);
+    const unsigned chunks = (n_upper + 63u) / 64u;
+    unsigned hw = cached;
+    if (n_estimate) hw = std::min<unsigned>(hw, std::max<unsigned>(64u, (n_estimate + n_estimate / 4 + 63u) / 64u));
+    const unsigned slots = ctx.refill ? std::min(ctx.refill_slots ? ctx.refill_slots : hw, chunks) : chunks;
+    if (!slots) return;
+    hipLaunchKernelGGL(kernel, dim3(slots), dim3(TRACE_BLOCK), lds, s, S, q, qg, t_min, t_max, hb, d_counters, sh);
+}
 static void launch_walk_any(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, uint32_t n_estimate, double t_min, double t_max,
                             HitBuf hb, bool stats, unsigned long long* d_counters, const WalkShade* sh, const StackOverflow& ovf,
                             hipStream_t s) {
     if (!n_upper) return;
+    if (S.pool8 && S.depth8 <= (uint32_t)BVH8_MAX_DEPTH) {
+        WalkShade w;
+        if (sh) w = *sh; else memset(&w, 0, sizeof(w));
+        w.stack_ovf = nullptr;
+        if (sh) {
+            if (stats) launch_walk8_k<true, true>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, s);
+            else launch_walk8_k<false, true>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, s);
+        } else {
+            if (stats) launch_walk8_k<true, false>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, s);
+            else launch_walk8_k<false, false>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, d_counters, w, s);
+        }
+        return;
+    }
     if (S.stack4 <= (uint32_t)BVH4_MAX_STACK) {
         if (S.nodes4) { launch_walk_b<Box16, 4>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
         if (S.nodes4f) { launch_walk_b<Box32, 4>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s); return; }
@@ -1213,7 +1494,7 @@ static void launch_walk_any(LaunchCtx& ctx, const DScene& S, RayQueue q, const Q
         launch_walk_b<Box64, 2>(ctx, S, q, qg, n_upper, n_estimate, t_min, t_max, hb, stats, d_counters, sh, ovf, s);
 }
 uint32_t stack_overflow_rows(const DScene& S, uint32_t lds_rows) {
-    const bool w4 = S.stack4 <= (uint32_t)BVH4_MAX_STACK && (S.nodes4 || S.nodes4f);
+    const bool w4 = !S.pool8 && S.stack4 <= (uint32_t)BVH4_MAX_STACK && (S.nodes4 || S.nodes4f);
     return (w4 && S.stack4 > lds_rows) ? S.stack4 - lds_rows : 0u;
 }
 void launch_walk(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,

@@ -1,6 +1,7 @@
 // rt_layout.h — HBM data layout of a flattened scene and of the wavefront path state.
 // Shared by the host flattening code, the BVH builder and the kernels (all part of librt_hip.so).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/rt_hip.h"
@@ -76,11 +77,16 @@ struct alignas(128) Node4f {
 };
 static_assert(sizeof(Node4f) == 128, "Node4f layout");
 
+// Primitive records: 80 bytes each, triangles and spheres alike, so that one array — and, for the BVH8 walk, one pool
+// of 80-byte records holding nodes AND primitives — is addressed with one stride.  `kind` (the last word of either
+// record) says which it is: the BVH8 walk reads it from the record it fetched, the other walks know it from the
+// leaf reference.
+enum { PRIM_KIND_TRIANGLE = 0, PRIM_KIND_SPHERE = 1 };
 // Triangle geometry in leaf order: a, e1 = b - a, e2 = c - a (src/hittable.rs:412-413), f64.
 struct alignas(16) TriGeom {
     double a[3], e1[3], e2[3];
     uint32_t prim;      // index in the caller's [spheres..., triangles...] order
-    uint32_t _pad;
+    uint32_t kind;      // PRIM_KIND_TRIANGLE
 };
 static_assert(sizeof(TriGeom) == 80, "TriGeom layout");
 
@@ -89,9 +95,37 @@ struct alignas(16) SphGeom {
     double c[3], r;
     double rot2[3];
     uint32_t prim;
-    uint32_t _pad;
+    uint32_t _pad[4];
+    uint32_t kind;      // PRIM_KIND_SPHERE (same offset as TriGeom::kind)
 };
-static_assert(sizeof(SphGeom) == 64, "SphGeom layout");
+static_assert(sizeof(SphGeom) == 80 && offsetof(SphGeom, kind) == offsetof(TriGeom, kind), "SphGeom layout");
+constexpr uint32_t PRIM_RECORD_BYTES = 80;
+
+// BVH8 node for incoherent rays (scenes of any size; the format of choice beyond the caches, where a walk is bound by
+// dependent memory round trips): one 80-byte record of the pool [nodes and primitives interleaved], after Ylitie,
+// Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs" (HPG 2017) — re-designed for
+// this walk (one fetch per step, f64 primitive tests, leaves of up to four primitives):
+//   - the boxes of up to eight children as 8-bit planes on a grid LOCAL to the node: plane = origin[k] + q * 2^(ex[k]-127),
+//     origin = the node box's lower corner rounded down to f32, the exponent the smallest that reaches the upper corner
+//     with q <= 255; the builder checks in 64-bit-mantissa arithmetic that these planes enclose every child box.
+//   - ONE base: the node's internal children are the records base, base+1, ... (in slot order), its leaf children's
+//     primitives the records right behind them (slot order, a leaf's primitives in a row).  inib has nibble s = 0xF when
+//     slot s is an internal child; pmask has bit 4s+j set when slot s is a leaf with more than j primitives.
+//   - slots are assigned so that visiting them in ascending order of (slot XOR octant of the ray direction) is roughly
+//     front to back: no sort in the kernel.
+struct alignas(16) Node8 {
+    float origin[3];
+    uint8_t ex[3];           // biased exponents of the cell sizes (uint_as_float(ex << 23) = 2^(ex-127))
+    uint8_t _pad0;
+    uint32_t base;           // record index of the first internal child
+    uint32_t inib;           // internal-child slots, one nibble each
+    uint32_t pmask;          // primitives of the leaf slots, one nibble each
+    uint32_t _pad1;
+    uint8_t qlo[3][8];       // [axis][slot]
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(Node8) == 80, "Node8 layout");
+constexpr int BVH8_MAX_DEPTH = 24;    // levels of internal nodes a BVH8 walk kernel provides stack for (two words each)
 
 // Shading records, indexed by primitive id (original order).
 struct alignas(16) TriShade {
@@ -127,6 +161,9 @@ struct DScene {
     const Node16* nodes16;       // optional (null when quantisation would inflate the leaves too much)
     const Node4* nodes4;         // optional: BVH4 over the same leaves, same grid (per-lane traversal prefers it)
     const Node4f* nodes4f;       // optional: BVH4 with f32 boxes, when there is no grid
+    const char* pool8;           // optional: the BVH8 walk's pool of 80-byte records (Node8, TriGeom, SphGeom); record 0 = root.
+                                 // tris and sphs then both point at it and the BVH2 arrays' leaf references count its records.
+    uint32_t depth8;             // levels of internal BVH8 nodes below the root = (base, pending) pairs its walk can hold at once
     const TriGeom* tris;
     const SphGeom* sphs;
     const TriShade* tri_shade;   // [n_triangles], index = prim - n_spheres

@@ -50,6 +50,90 @@ static B3 walk(const BvhResult& r, const std::vector<PrimBox>& boxes, size_t n_s
     return b;
 }
 
+// ---- BVH8 (bvh_wide8.cpp): walks the record layout from the root; returns the exact bounds of the subtree.  Checks: a
+// node's internal children are the records base, base+1, ... in slot order and its leaves' primitives follow them; the
+// planes origin + q * 2^(ex-127) of every child slot enclose that child's primitives (the grid is node-local, so this
+// is checked against the true bounds, in 64-bit-mantissa arithmetic); every primitive record is reached exactly once.
+struct Pool8View {
+    const Wide8& w;
+    std::vector<int32_t> node_at;        // record -> node index, -1 otherwise
+    std::vector<int32_t> prim_at;        // record -> primitive (caller's order), -1 otherwise
+};
+static B3 walk8(const Pool8View& v, const std::vector<PrimBox>& boxes, uint32_t rec, uint32_t level, std::vector<int>& seen, uint32_t& max_level,
+                size_t& n_nodes) {
+    B3 all = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+    CHECK(rec < v.node_at.size() && v.node_at[rec] >= 0, "record %u is not a node", rec);
+    if (rec >= v.node_at.size() || v.node_at[rec] < 0) return all;
+    const Node8& nd = v.w.nodes[(size_t)v.node_at[rec]];
+    ++n_nodes;
+    max_level = std::max(max_level, level);
+    uint32_t n_int = 0;
+    for (int s = 0; s < 8; ++s) n_int += ((nd.inib >> (4 * s)) & 0xF) ? 1 : 0;
+    uint32_t child_rec = nd.base, prim_rec = nd.base + n_int;
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t in = (nd.inib >> (4 * s)) & 0xF, pm = (nd.pmask >> (4 * s)) & 0xF;
+        CHECK(in == 0 || in == 0xF, "inib nibble %x", in);
+        CHECK(!(in && pm), "slot %d is both internal and leaf", s);
+        CHECK(pm == 0 || pm == 1 || pm == 3 || pm == 7 || pm == 15, "pmask nibble %x", pm);
+        if (!in && !pm) continue;
+        B3 b = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+        if (in) {
+            b = walk8(v, boxes, child_rec++, level + 1, seen, max_level, n_nodes);
+        } else {
+            for (uint32_t j = 0; j < 4 && ((pm >> j) & 1); ++j) {
+                CHECK(prim_rec < v.prim_at.size() && v.prim_at[prim_rec] >= 0, "record %u is not a primitive", prim_rec);
+                if (prim_rec < v.prim_at.size() && v.prim_at[prim_rec] >= 0) {
+                    const int p = v.prim_at[prim_rec];
+                    seen[p]++;
+                    for (int a = 0; a < 3; ++a) { b.lo[a] = std::fmin(b.lo[a], boxes[p].lo[a]); b.hi[a] = std::fmax(b.hi[a], boxes[p].hi[a]); }
+                }
+                ++prim_rec;
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            const long double lo = (long double)nd.origin[a] + std::ldexp((long double)nd.qlo[a][s], (int)nd.ex[a] - 127);
+            const long double hi = (long double)nd.origin[a] + std::ldexp((long double)nd.qhi[a][s], (int)nd.ex[a] - 127);
+            CHECK(lo <= (long double)b.lo[a] && hi >= (long double)b.hi[a], "BVH8 node at record %u slot %d axis %d does not enclose its child", rec, s, a);
+            CHECK(nd.ex[a] >= 1 && nd.ex[a] <= 254, "exponent byte %u", nd.ex[a]);
+            all.lo[a] = std::fmin(all.lo[a], b.lo[a]); all.hi[a] = std::fmax(all.hi[a], b.hi[a]);
+        }
+    }
+    return all;
+}
+static void check_wide8(const char* what, const BvhResult& r, const std::vector<PrimBox>& boxes, size_t n_spheres) {
+    Wide8 w;
+    if (r.nodes.empty()) return;
+    const bool ok = widen_nodes8(r.nodes, r.tri_order.size(), r.sph_order.size(), w);
+    CHECK(ok, "%s: widen_nodes8 failed", what);
+    if (!ok) return;
+    CHECK(w.n_records == w.nodes.size() + boxes.size(), "%s: %zu records for %zu nodes + %zu primitives", what, w.n_records, w.nodes.size(), boxes.size());
+    Pool8View v{w, std::vector<int32_t>(w.n_records, -1), std::vector<int32_t>(w.n_records, -1)};
+    size_t clash = 0;
+    for (size_t i = 0; i < w.nodes.size(); ++i) { clash += v.node_at[w.node_rec[i]] >= 0; v.node_at[w.node_rec[i]] = (int32_t)i; }
+    for (size_t k = 0; k < w.tri_rec.size(); ++k) { clash += v.node_at[w.tri_rec[k]] >= 0 || v.prim_at[w.tri_rec[k]] >= 0; v.prim_at[w.tri_rec[k]] = (int32_t)(r.tri_order[k] + n_spheres); }
+    for (size_t k = 0; k < w.sph_rec.size(); ++k) { clash += v.node_at[w.sph_rec[k]] >= 0 || v.prim_at[w.sph_rec[k]] >= 0; v.prim_at[w.sph_rec[k]] = (int32_t)r.sph_order[k]; }
+    CHECK(clash == 0, "%s: %zu records assigned twice", what, clash);
+    CHECK(w.node_rec[0] == 0, "%s: the root is not record 0", what);
+    std::vector<int> seen(boxes.size(), 0);
+    uint32_t max_level = 0;
+    size_t n_nodes = 0;
+    walk8(v, boxes, 0, 1, seen, max_level, n_nodes);
+    size_t bad = 0;
+    for (int s : seen) bad += s != 1;
+    CHECK(bad == 0, "%s: %zu primitives not under exactly one BVH8 leaf slot", what, bad);
+    CHECK(n_nodes == w.nodes.size() && max_level == w.depth, "%s: BVH8 walk saw %zu nodes / %u levels, builder says %zu / %u", what, n_nodes, max_level, w.nodes.size(), w.depth);
+    // a BVH2 leaf's primitives stay in a row (the BVH2 arrays address them as first, first+1, ...)
+    for (const Node64& nd : r.nodes)
+        for (uint32_t ref : {nd.left, nd.right}) {
+            if (ref == REF_EMPTY || !(ref & REF_LEAF)) continue;
+            const std::vector<uint32_t>& map = (ref & REF_SPHERE) ? w.sph_rec : w.tri_rec;
+            const uint32_t first = ref & REF_FIRST_MASK, cnt = ((ref >> 28) & 3u) + 1u;
+            for (uint32_t j = 1; j < cnt; ++j) CHECK(map[first + j] == map[first] + j, "%s: leaf primitives not in a row", what);
+        }
+    printf("%-28s BVH8: %zu nodes, %u levels, %.2f children per node\n", what, w.nodes.size(), w.depth,
+           w.nodes.empty() ? 0.0 : (double)(w.nodes.size() - 1 + r.nodes.size() + 1) / (double)w.nodes.size());
+}
+
 static size_t last_nodes = 0;
 static uint32_t last_depth = 0;
 static std::vector<uint32_t> last_tri_order, last_sph_order;
@@ -104,6 +188,7 @@ static void check_tree(const char* what, const std::vector<PrimBox>& boxes, size
     std::vector<Node4f> n4f;
     uint32_t need_f = 0;
     if (!r.nodes.empty()) CHECK(widen_nodes_f32(r.nodes, n4f, need_f), "%s: widen_nodes_f32 failed", what);
+    check_wide8(what, r, boxes, n_spheres);
     printf("%-28s n=%8zu nodes=%8zu depth=%2u max_leaf=%u\n", what, boxes.size(), r.nodes.size(), r.depth, r.max_leaf);
 }
 
@@ -121,6 +206,18 @@ int main() {
     check_tree("three triangles", random_boxes(3), 0);
     check_tree("mixed small", random_boxes(37), 11);
     check_tree("mixed 50k (sequential)", random_boxes(50000), 7000);
+    {   // far from the origin with tiny extents, flat boxes (a ground plane's triangles), a huge box next to small ones:
+        // the node-local grids must still enclose (exponent clamps, origin rounding)
+        std::vector<PrimBox> b = random_boxes(3000);
+        for (size_t i = 0; i < b.size(); ++i)
+            for (int a = 0; a < 3; ++a) {
+                if (i % 3 == 0) { b[i].lo[a] = 1.0e6 + 1e-4 * b[i].lo[a]; b[i].hi[a] = 1.0e6 + 1e-4 * b[i].hi[a]; }
+                if (i % 5 == 0 && a == 2) b[i].hi[a] = b[i].lo[a];
+            }
+        for (int a = 0; a < 3; ++a) { b[7].lo[a] = -1.0e4; b[7].hi[a] = 1.0e4; }
+        b[8].lo[0] = b[8].hi[0] = 0.0;
+        check_tree("awkward boxes", b, 500);
+    }
     {   // coincident primitives: every SAH split is degenerate
         std::vector<PrimBox> b(5000, random_boxes(1)[0]);
         check_tree("5000 coincident", b, 100);

@@ -253,34 +253,39 @@ def test_exact_ties_keep_t_bit_exact(cover, oracle):
 def test_node_formats_agree(monkeypatch, oracle):
     """RT_HIP_NODE_BOXES selects exact f64 boxes, conservative f32 boxes, or f32 boxes quantised to a
     16-bit grid, as BVH2 (q16) or collapsed to a BVH4 (w4: default for the per-lane traversal when the
-    grid is fine enough).  Boxes only cull: all formats must give the same hits and the same image, bit for bit."""
+    grid is fine enough), or the BVH8 with 8-bit boxes on node-local grids and octant-ordered children (w8: its own walk
+    kernel, its own record pool shared with the camera-ray kernel's BVH2).  Boxes only cull: all formats must give the
+    same hits and the same image, bit for bit."""
     desc = scenes.mixed_test_scene(seed=5, n_spheres=60, quads=40)
     worlds = {}
-    for fmt in ("w4", "w4f", "q16", "f32", "f64"):
+    for fmt in ("w8", "w4", "w4f", "q16", "f32", "f64"):
         monkeypatch.setenv("RT_HIP_NODE_BOXES", fmt)
         worlds[fmt] = World.build(desc)
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
     worlds["default"] = World.build(desc)
-    assert [worlds[f].info()["node_bytes"] for f in ("w4", "w4f", "q16", "f32", "f64")] == [64, 128, 32, 64, 128]
-    assert [worlds[f].info()["bvh_width"] for f in ("default", "w4", "w4f", "q16", "f32", "f64")] == [4, 4, 4, 2, 2, 2]
+    assert [worlds[f].info()["node_bytes"] for f in ("w8", "w4", "w4f", "q16", "f32", "f64")] == [80, 64, 128, 32, 64, 128]
+    assert [worlds[f].info()["bvh_width"] for f in ("default", "w8", "w4", "w4f", "q16", "f32", "f64")] == [4, 8, 4, 4, 2, 2, 2]
     rays = np.concatenate([random_rays(40_000, 17), degenerate_rays(desc, 6)])
     hits = {f: w.hit(rays) for f, w in worlds.items()}
     assert_hits_equal(hits["f32"], hits["f64"])
     assert_hits_equal(hits["q16"], hits["f64"])
     assert_hits_equal(hits["w4"], hits["f64"])
     assert_hits_equal(hits["w4f"], hits["f64"])
+    assert_hits_equal(hits["w8"], hits["f64"])
     assert_hits_equal(hits["default"], hits["f64"])
     assert_hits_equal(hits["q16"], oracle.OracleScene(desc).hit(rays, mode=oracle.BVH_PRUNE))
     # on ordinary rays the wider margins / coarser boxes accept only a few extra nodes
     nv = {f: int(w.hit(rays[:40_000], with_stats=True)[1]["nodes_visited"]) for f, w in worlds.items()}
     assert nv["f64"] <= nv["f32"] <= nv["f64"] * 1.01 and nv["f32"] <= nv["q16"] <= nv["f32"] * 1.10
     assert nv["w4"] < 0.7 * nv["q16"]                      # a BVH4 visit replaces about two BVH2 visits
+    assert nv["w8"] < 0.85 * nv["w4"]                      # and a BVH8 visit about 1.3 BVH4 visits (octant order, no sort)
     cam = Camera.new((9.0, -7.0, 4.0), (0.0, 0.0, 0.8), (0.0, 0.0, 1.0), 10.0, 0.3, 96, 64, 4, 12, 35.0)
     img = cam.render_image(worlds["f64"], spp=3, seed=2)
     assert np.array_equal(cam.render_image(worlds["f32"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["q16"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["w4"], spp=3, seed=2), img)
     assert np.array_equal(cam.render_image(worlds["w4f"], spp=3, seed=2), img)
+    assert np.array_equal(cam.render_image(worlds["w8"], spp=3, seed=2), img)
 
 
 def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypatch, cover, oracle):
@@ -301,6 +306,15 @@ def test_coarse_grid_is_rejected_by_default_and_still_exact_when_forced(monkeypa
     monkeypatch.delenv("RT_HIP_NODE_BOXES")
     assert forced4.info()["bvh_width"] == 4
     assert_hits_equal(forced4.hit(rays), ref)
+    # the BVH8's grids are local to each node: the huge ground plane costs it nothing (spheres, a few triangles,
+    # defocus camera: the whole render path on the other walk)
+    monkeypatch.setenv("RT_HIP_NODE_BOXES", "w8")
+    w8 = World.build(desc)
+    monkeypatch.delenv("RT_HIP_NODE_BOXES")
+    assert w8.info()["bvh_width"] == 8
+    assert_hits_equal(w8.hit(rays), ref)
+    cam = scenes.cover_camera(128, 72, spp=4, max_depth=50, defocus=True)
+    assert np.array_equal(cam.render_image(w8, spp=4, seed=6), cam.render_image(world, spp=4, seed=6))
 
 
 def test_converged_image_relmse_at_4096_spp(cover, oracle):
