@@ -110,26 +110,31 @@ def cpu_baseline(desc, cam, target_seconds):
             "value_with_distance_pruning": samples / dt_prune / 1e6}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the two traversal kernels, from the newest committed PMC summary of this workload
-    (profiles/*_traffic_<workload>.json, written by tools/pmc_summary.py from separate --pmc passes; FETCH_SIZE
-    doubled for gfx950).  PMC passes cannot run inside the timed bench, so this is the committed measurement or None."""
+def pmc_profile(workload):
+    """What the newest committed PMC summary of this workload says about the traversal kernels
+    (profiles/*_traffic_<workload>.json, written by tools/pmc_summary.py from separate rocprofv3 --pmc passes of this same
+    bench command; PMC passes cannot run inside the timed bench).  Returns (walk kernel record, camera kernel record,
+    file name, VALU activity of the four main kernels); records are {} when there is no file."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                           "*_traffic_%s.json" % workload.replace("_", ""))))
     if not files:
-        return None, None, None, None
+        return {}, {}, None, None
     k = json.load(open(files[-1]))["kernels"]
-    def pick(pre, key="traffic_bytes_per_launch", suf=""):
-        return next((v.get(key) for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"])
-                     if n.startswith(pre) and n.rstrip().endswith(suf)), None)
 
-    # stand-alone traversal = k_walk<...> (the r01 summaries name it k_trace4); persistent trace-and-shade = k_walk_shade<...>
-    walk = lambda key: pick("k_walk<", key) if pick("k_walk<", key) is not None else pick("k_trace4<", key)
-    valu = {"k_walk": walk("valu_active_per_simd_cycle"), "k_walk_shade": pick("k_walk_shade<", "valu_active_per_simd_cycle"),
-            "k_trace_packet": pick("k_trace_packet", "valu_active_per_simd_cycle"),
-            "k_shade": pick("k_shade", "valu_active_per_simd_cycle")}
-    return walk("traffic_bytes_per_launch"), pick("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
+    def rec(pre):
+        return next((v for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"]) if n.startswith(pre)), {})
+
+    walk = rec("k_walk<") or rec("k_walk8<") or rec("k_trace4<")
+    for r in (walk, rec("k_trace_packet")):          # summaries written before round 3 carry one (doubled) figure
+        if r and "l2_fabric_bytes_per_launch_low" not in r and "fetch_bytes_per_launch_raw" in r:
+            r["l2_fabric_bytes_per_launch_low"] = r["fetch_bytes_per_launch_raw"] + r.get("write_bytes_per_launch", 0.0)
+            r["l2_fabric_bytes_per_launch_high"] = 2.0 * r["fetch_bytes_per_launch_raw"] + r.get("write_bytes_per_launch", 0.0)
+    valu = {"k_walk": walk.get("valu_active_per_simd_cycle"),
+            "k_walk_shade": (rec("k_walk_shade<") or rec("k_walk8_shade<")).get("valu_active_per_simd_cycle"),
+            "k_trace_packet": rec("k_trace_packet").get("valu_active_per_simd_cycle"),
+            "k_shade": rec("k_shade").get("valu_active_per_simd_cycle")}
+    return walk, rec("k_trace_packet"), "profiles/" + os.path.basename(files[-1]), valu
 
 
 def visible_gpus():
@@ -397,7 +402,7 @@ def main():
         a_on = min(1.0, (int(sst["ray_segments"]) - s_pseg - int(sst["tail_segments"])) / s_pseg)      # share of camera rays that go on
         p_bytes_per_wave = wv_n * 64 + wv_p * prim_bytes + 64 * (24 * (1 - a_on) + 76 * a_on)
         p_achieved = (prim_seg / 64.0) * p_bytes_per_wave / prim_s / 1e9 if prim_s > 0 else 0.0
-        traffic, p_traffic, traffic_src, valu = pmc_traffic(args.workload)
+        pmc_walk, pmc_cam, pmc_src, valu = pmc_profile(args.workload)
         roof_alone = None
         if alone is not None:
             a_s, a_seg = float(alone["seconds_trace_bounce"]), int(alone["bounce_segments"])
@@ -408,6 +413,14 @@ def main():
                           "tail_kernel_rays_per_s": int(alone["tail_segments"]) / max(float(alone["seconds_tail"]), 1e-12),
                           "ms_per_frame": float(alone["seconds_total"]) * 1e3}
         k_valu = (valu or {}).get("k_walk")
+        seg_per_launch = bounce_seg / max(1, bounce_launches)
+        insts = pmc_walk.get("valu_instructions_per_launch")
+        fabric = None
+        if pmc_walk.get("l2_fabric_bytes_per_launch_low") is not None:
+            fabric = [pmc_walk["l2_fabric_bytes_per_launch_low"], pmc_walk["l2_fabric_bytes_per_launch_high"]]
+        cam_fabric = None
+        if pmc_cam.get("l2_fabric_bytes_per_launch_low") is not None:
+            cam_fabric = [pmc_cam["l2_fabric_bytes_per_launch_low"], pmc_cam["l2_fabric_bytes_per_launch_high"]]
         out = {
             "metric": "Msamples/s, 1080p 1M-tri mesh scene" if args.workload == "heightfield_1m" else f"Msamples/s, {args.workload}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -418,29 +431,46 @@ def main():
                        "n_prims": info["n_prims"]},
             "rays_per_s": rays_per_s, "segments_per_sample": float(seg.item()) / (samples_per_step * args.steps),
             "launches_per_step": S("launches") / args.steps, "passes_per_step": n_passes / args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         # which bound binds: the scene (BVH + triangles) is resident in L2 / Infinity Cache, measured HBM traffic is a
-                         # fraction of the algorithmic bytes, and the kernel is limited by VALU issue (rocprofv3 SQ_ACTIVE_INST_VALU per
-                         # SIMD-cycle, same committed PMC summary)
-                         "binding_bound": "valu_issue", "valu_active_per_simd_cycle": valu,
-                         "valu_roofline": {"achieved": k_valu, "peak": 1.0, "unit": "VALU-active wave-cycles per SIMD-cycle", "frac": k_valu},
+            # The bound that binds.  The dominant kernel — k_walk on the first-bounce queue — runs out of VALU issue slots, not
+            # out of memory bandwidth: its scene is served by L2 + Infinity Cache (roofline_hbm_nominal below prices the
+            # ALGORITHMIC bytes against the HBM peak and overshoots what any memory level delivers), and rocprofv3's
+            # SQ_ACTIVE_INST_VALU says the vector ALUs are busy `achieved` of every SIMD-cycle at ~3 resident waves per SIMD
+            # (a wave64 VALU instruction occupies its SIMD for 4 cycles, f64 and f32 alike on gfx950:
+            # profiles/r03_b_valu_issue_rates.txt).  achieved / frac come from the committed PMC summary named in `source`
+            # (separate --pmc passes of this same command; counters cannot be read inside the timed run); the launch
+            # duration, segments and rays/s beside them are measured live here with HIP events on the kernel's stream.
+            "roofline": {"bound": "valu_issue", "achieved": k_valu, "peak": 1.0,
+                         "unit": "VALU-active wave-cycles per SIMD-cycle (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024))",
+                         "frac": k_valu, "traffic": None, "source": pmc_src,
+                         "valu_active_per_simd_cycle": valu,
+                         "valu_lane_utilisation": pmc_walk.get("valu_lane_utilisation"),
+                         "valu_instructions_per_launch": insts,
+                         # wave-level VALU instructions per 64 ray segments: the floor a faster kernel has to lower
+                         # (tools/asm_blocks.py counts ~500 per wave iteration: 60 loop head + 196 node step + 248 primitive step)
+                         "valu_instructions_per_64_segments": (insts / seg_per_launch * 64.0) if insts and seg_per_launch else None,
                          "kernel": "k_walk (per-lane BVH%d traversal of the first-bounce queue, one launch per pass)" % info.get("bvh_width", 4),
                          "avg_launch_ms": bounce_s / max(1, bounce_launches) * 1e3, "launches": bounce_launches,
-                         "segments": bounce_seg, "bytes_per_segment": bytes_per_seg, "nodes_per_segment": v_n,
-                         "prims_per_segment": v_p, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
+                         "segments": bounce_seg, "nodes_per_segment": v_n, "prims_per_segment": v_p,
                          "rays_per_s": bounce_seg / bounce_s if bounce_s > 0 else 0.0,
-                         # the same kernel with one pass in flight (one extra untimed frame after the timed region)
                          "alone": roof_alone,
-                         "note": ("BVH+triangles (%.0f MB) %s; several passes run on their own streams in the timed region, so its "
-                                  "event-timed kernel durations include time shared with the other passes; 'alone' is the same kernel "
-                                  "with one pass in flight") % (info["device_bytes"] / 2 ** 20,
-                                  "are resident in L2/Infinity Cache, so algorithmic bytes/s may exceed the HBM peak"
-                                  if info["device_bytes"] <= 256 << 20 else
-                                  "exceed the 256 MB Infinity Cache: the top of the tree is served by the caches, the rest by HBM "
-                                  "(compare 'traffic', the measured HBM bytes per launch, with achieved x avg_launch_ms)")},
+                         "note": "several passes run on their own streams in the timed region, so the event-timed kernel durations include time "
+                                 "shared with the other passes; 'alone' is the same kernel with one pass in flight"},
+            # The memory-side figure, NOMINAL: algorithmic bytes (ray in + hit out + nodes and primitives
+            # visited x record size) over the live launch duration, against the 8 TB/s HBM peak.  l2_fabric_bytes is what
+            # the L2 actually requested from the fabric per launch (FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits included, so
+            # this is L2-miss traffic, not HBM traffic; [low, high] = every read request counted as 64 / as 128 bytes:
+            # profiles/r03_a_fetch_size_calibration_gather.txt).
+            "roofline_hbm_nominal": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": achieved / HBM_PEAK_GBS, "l2_fabric_bytes": fabric, "source": pmc_src,
+                                     "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch,
+                                     "bytes_per_segment": bytes_per_seg, "node_bytes": info["node_bytes"], "prim_bytes": prim_bytes,
+                                     "alone": ({"achieved": roof_alone["achieved"], "frac": roof_alone["frac"]} if roof_alone else None),
+                                     "note": ("BVH + primitives (%.0f MB) %s") % (info["device_bytes"] / 2 ** 20,
+                                              "are resident in L2 / Infinity Cache: algorithmic bytes per second may exceed the HBM peak"
+                                              if info["device_bytes"] <= 256 << 20 else
+                                              "exceed the 256 MB Infinity Cache: the top of the tree is served by the caches, the rest by HBM")},
             "roofline_packet": {"bound": "hbm", "achieved": p_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": p_achieved / HBM_PEAK_GBS, "traffic": p_traffic,
+                                "frac": p_achieved / HBM_PEAK_GBS, "l2_fabric_bytes": cam_fabric, "nominal": True,
                                 "kernel": "k_trace_packet (camera rays: raygen + packet traversal + depth-0 shading); bytes counted per WAVE "
                                           "(a wave fetches each node / primitive once for its 64 rays)",
                                 "avg_launch_ms": prim_s / max(1, n_passes) * 1e3, "launches": n_passes, "segments": prim_seg,

@@ -16,7 +16,12 @@
 namespace rt {
 namespace {
 
-constexpr int NBINS = 16;
+#ifndef RT_NBINS
+#define RT_NBINS 16
+#endif
+// (32 bins, or an exact sweep over the sorted centroids for ranges of up to 64 / 512 primitives, change the node visits per
+// ray by less than 0.5 % on the 1 M and the 5 M triangle scenes: A/B of round 3)
+constexpr int NBINS = RT_NBINS;
 constexpr double COST_TRAVERSE = 1.0;
 #ifndef RT_COST_PRIM
 #define RT_COST_PRIM 1.0

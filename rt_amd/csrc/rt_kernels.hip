@@ -1266,6 +1266,44 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const double* path_radianc
     rgb_sum[3 * (size_t)pixel] = r; rgb_sum[3 * (size_t)pixel + 1] = g; rgb_sum[3 * (size_t)pixel + 2] = b;
 }
 
+// The same sums for the usual layout (16 samples of a pixel per wave of camera rays, rt_device.h: slot_sample_to_pid):
+// there the 64 paths with consecutive ids are 16 samples of 4 neighbouring pixel slots, so a thread of k_accumulate that
+// follows ONE pixel through its samples reads 24 bytes here, 24 bytes 96 bytes further on, ...  Here a wave takes such a
+// block of 64 paths as it lies — 1536 contiguous bytes, three fully coalesced loads — through LDS, and twelve lanes
+// (4 pixels x 3 channels) add their 16 values in ascending sample order, sample group after sample group: the same
+// additions in the same order as k_accumulate, so the frame is the same bit for bit.  One small workgroup per block of
+// four pixels: 364 -> 327 us per pass at 1080p.  (A grid of resident waves striding over the blocks with the next block's
+// loads in flight streams faster on its own but cost the frame 6 %: the passes' sums are ordered through events, and
+// long-lived waves of one pass's sum kernel stand in the way of the next pass's.)
+__global__ __launch_bounds__(64) void k_accumulate16(const double* path_radiance, uint32_t n_pixels, uint32_t W, uint32_t H, uint32_t n_local,
+                                                     double* rgb_sum, uint32_t* zero_counts, uint32_t n_zero) {
+    __shared__ double blk[192];
+    const uint32_t lane = threadIdx.x, b = blockIdx.x;                  // b: block of four pixel slots 4b .. 4b+3
+    const uint32_t gid = b * 64u + lane;
+    if (zero_counts && gid < n_zero) zero_counts[gid] = 0u;
+    if (4u * b >= n_pixels) return;                                     // (wave-uniform)
+    const uint32_t j = lane / 3u, c = lane - 3u * j;                    // lanes 0..11: pixel slot 4b + j, channel c
+    size_t at = 0;
+    double acc = 0.0;
+    if (lane < 12u) {
+        at = 3 * (size_t)slot_to_pixel(4u * b + j, W, H, 1u) + c;
+        acc = rgb_sum[at];
+    }
+    const size_t group_stride = (size_t)n_pixels * 16u * 3u;            // doubles between two sample groups of the same block
+    const double* src = path_radiance + (size_t)b * 192u;
+    for (uint32_t sg = 0; sg < n_local / 16u; ++sg, src += group_stride) {
+        const double v0 = src[lane], v1 = src[lane + 64u], v2 = src[lane + 128u];
+        __syncthreads();                                                // (one wave: the barrier only orders the LDS traffic)
+        blk[lane] = v0; blk[lane + 64u] = v1; blk[lane + 128u] = v2;
+        __syncthreads();
+        if (lane < 12u) {
+#pragma unroll
+            for (uint32_t s_ = 0; s_ < 16u; ++s_) acc += blk[(4u * s_ + j) * 3u + c];      // path 4 s + j of the block: sample s of pixel j
+        }
+    }
+    if (lane < 12u) rgb_sum[at] = acc;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_resolve(const double* sum, double* mean, size_t n, double total_spp) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) mean[i] = sum[i] / total_spp;             // `/ num_samples as Float` (src/camera.rs:324)
@@ -1566,6 +1604,12 @@ void launch_shade(const DScene& S, const PassParams& pp, uint32_t depth, RayQueu
 void launch_accumulate(const PassParams& pp, const double* d_path_radiance, uint32_t n_local, double* d_rgb_sum,
                        uint32_t* d_zero_counts, uint32_t n_zero, hipStream_t s) {
     if (!pp.n_pixels || !n_local) return;
+    if (pp.group == 16u && pp.tiled && n_local % 16u == 0 && pp.n_pixels % 4u == 0) {
+        const size_t blocks = std::max<size_t>(pp.n_pixels / 4u, d_zero_counts ? (n_zero + 63u) / 64u : 0);
+        hipLaunchKernelGGL(k_accumulate16, dim3((unsigned)blocks), dim3(64), 0, s, d_path_radiance, pp.n_pixels, pp.cam.width, pp.cam.height,
+                           n_local, d_rgb_sum, d_zero_counts, n_zero);
+        return;
+    }
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(std::max<size_t>(pp.n_pixels, d_zero_counts ? n_zero : 0))), dim3(BLOCK), 0, s,
                        d_path_radiance, pp.n_pixels, pp.cam.width, pp.cam.height, pp.tiled, pp.group, n_local, d_rgb_sum,
                        d_zero_counts, n_zero);

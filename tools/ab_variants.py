@@ -65,7 +65,8 @@ def run(args):
             j = json.loads(line[-1])
             rf = j["roofline"]
             print(f"{n:34s} r{rnd} value={j['value']:8.1f} ms/step={j['ms_per_step']:8.2f} "
-                  f"bounce_rays/s={rf['rays_per_s'] / 1e9:.3f}G packet_rays/s={j['roofline_packet']['rays_per_s'] / 1e9:.3f}G", flush=True)
+                  f"bounce_rays/s={rf['rays_per_s'] / 1e9:.3f}G packet_rays/s={j['roofline_packet']['rays_per_s'] / 1e9:.3f}G "
+                  f"nodes/seg={rf.get('nodes_per_segment', 0):.2f} prims/seg={rf.get('prims_per_segment', 0):.2f} build_s={j['scene']['bvh_build_s']:.2f}", flush=True)
 
 
 if __name__ == "__main__":

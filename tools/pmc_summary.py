@@ -42,9 +42,12 @@ for k in sorted(cnt, key=lambda k: -dur.get(k, [0, 0])[1]):
     print(f"{k:40s} {4.0 * c.get('SQ_ACTIVE_INST_VALU', 0.0) / simd_cycles:8.3f} {4.0 * c['SQ_WAVE_CYCLES'] / simd_cycles:8.2f} "
           f"{c.get('SQ_ACTIVE_INST_VALU', 0.0) / c['SQ_WAVE_CYCLES']:8.3f} "
           f"{c.get('TCC_HIT_sum', 0.0) / max(c.get('TCC_REQ_sum', 0.0), 1.0):8.3f}")
-# --traffic <out.json>: HBM-side bytes per launch of each kernel, FETCH_SIZE / WRITE_SIZE are reported in KiB;
-# FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B; calibrated
-# there for wide streaming reads only, so for these gather kernels it is an upper estimate of the correction).
+# --traffic <out.json>: bytes the L2 requested from the fabric per launch of each kernel.  FETCH_SIZE / WRITE_SIZE are reported
+# in KiB and are the L2's memory-side request counters (MI355X_MICROARCH.md, HBM): reads served by the Infinity Cache are
+# INCLUDED, so this is L2-miss traffic, not HBM traffic.  FETCH_SIZE tallies every request at 64 bytes: measured against known
+# bytes (profiles/r03_a_fetch_size_calibration_gather.txt) the factor is 0.96 for random 64-byte gathers and 1.89 for
+# 128-byte ones (the guide's x2 is for wide streaming reads), so both ends are given: low = FETCH x1 + WRITE (a kernel
+# of 64-byte gathers: the BVH4 walk's nodes), high = FETCH x2 + WRITE (every request a full 128-byte line).
 if len(sys.argv) > 3 and sys.argv[2] == "--traffic":
     import json
     n_disp = defaultdict(int)
@@ -56,9 +59,17 @@ if len(sys.argv) > 3 and sys.argv[2] == "--traffic":
     for k, n in n_disp.items():
         if not k.startswith("k_"):
             continue
-        fetch = cnt[k].get("FETCH_SIZE", 0.0) * 1024.0
-        write = cnt[k].get("WRITE_SIZE", 0.0) * 1024.0
+        c = cnt[k]
+        fetch = c.get("FETCH_SIZE", 0.0) * 1024.0
+        write = c.get("WRITE_SIZE", 0.0) * 1024.0
+        insts = c.get("SQ_INSTS_VALU", 0.0)
         out[k] = {"launches": n, "fetch_bytes_per_launch_raw": fetch / n, "write_bytes_per_launch": write / n,
-                  "traffic_bytes_per_launch": (2.0 * fetch + write) / n,
-                  "valu_active_per_simd_cycle": valu_active.get(k)}
+                  "l2_fabric_bytes_per_launch_low": (fetch + write) / n, "l2_fabric_bytes_per_launch_high": (2.0 * fetch + write) / n,
+                  "valu_active_per_simd_cycle": valu_active.get(k),
+                  # wave-level VALU instructions per launch, and the share of the 64 lanes that were enabled when they ran
+                  # (SQ_THREAD_CYCLES_VALU adds up the enabled lanes of every VALU instruction: k_jitter_table, 32 of 64
+                  # lanes at work, reads 0.50)
+                  "valu_instructions_per_launch": insts / n if insts else None,
+                  "valu_lane_utilisation": (c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * insts)) if insts else None,
+                  "l2_hit_rate": (c.get("TCC_HIT_sum", 0.0) / c["TCC_REQ_sum"]) if c.get("TCC_REQ_sum") else None}
     json.dump({"source": os.path.basename(d.rstrip("/")), "kernels": out}, open(sys.argv[3], "w"), indent=1)

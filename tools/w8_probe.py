@@ -22,7 +22,10 @@ for fmt in ("0", "1"):
     info = w.info()
     print(f"BVH8={fmt}: create {time.time() - t0:.2f} s (build {info['build_seconds']:.2f}, upload {info['upload_seconds']:.2f}), width {info['bvh_width']}, "
           f"node bytes {info['node_bytes']}, device MB {info['device_bytes'] / 2**20:.0f}", flush=True)
+    os.environ["RT_HIP_DEBUG_UTIL"] = "1"
+    os.environ["RT_HIP_PIPES"] = "1"
     _, st = cam.render_image(w, spp=4, seed=1, with_stats=True, collect_stats=True)
+    os.environ.pop("RT_HIP_DEBUG_UTIL"); os.environ.pop("RT_HIP_PIPES")
     bs = max(1, int(st["bounce_segments"]))
     print(f"   first bounce: {int(st['nodes_visited_bounce']) / bs:.2f} nodes, {int(st['prims_tested_bounce']) / bs:.2f} primitives per segment; "
           f"all: {(int(st['nodes_visited']) - int(st['nodes_visited_primary'])) / max(1, int(st['ray_segments']) - int(st['primary_segments'])):.2f} nodes per non-camera segment", flush=True)
