@@ -11,8 +11,10 @@ export TMPDIR=/tmp
 cd /tmp
 ARGS="$ROOT/bench.py --no-cpu-baseline --no-alone --steps 1 --warmup 0 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
+# RT_PROF_PASSES="sq1 sq2 tcc1 tcc2 grbm" (optional): only these passes (scenes that take a minute to generate)
 pass() {
   name=$1; shift
+  if [ -n "${RT_PROF_PASSES:-}" ]; then case " $RT_PROF_PASSES " in *" $name "*) ;; *) return 0;; esac; fi
   timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1 || exit 1
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
