@@ -177,6 +177,7 @@ struct Shared {
     std::vector<uint32_t> idx;
     std::vector<double> cent;      // 3 per prim
     std::vector<uint32_t> spare;   // the stable partition's second buffer (a builder uses the range it owns in idx)
+    size_t first_solo = SIZE_MAX;  // items from this index on never share a leaf (build_bvh_grouped: the groups' boxes)
     Shared(const std::vector<PrimBox>& b, size_t ns, Team& team) : pb(b), nsph(ns) {
         idx.resize(b.size());
         cent.resize(3 * b.size());
@@ -200,8 +201,10 @@ struct Builder {
     size_t task_threshold = 0;
     std::vector<uint32_t>& spare;   // shared like idx: the stable partition's second buffer, same ranges
     Team* team = nullptr;           // set for the builder of the top of the tree (the only one running at that time)
+    size_t first_solo;
 
-    Builder(Shared& sh, BvhResult& o) : pb(sh.pb), nsph(sh.nsph), idx(sh.idx), cent(sh.cent), out(o), spare(sh.spare) {}
+    Builder(Shared& sh, BvhResult& o)
+        : pb(sh.pb), nsph(sh.nsph), idx(sh.idx), cent(sh.cent), out(o), spare(sh.spare), first_solo(sh.first_solo) {}
 
     void each_piece(size_t n_pieces, const std::function<void(size_t)>& fn) const {
         if (team) team->run(n_pieces, fn);
@@ -210,8 +213,9 @@ struct Builder {
 
     bool homogeneous(size_t first, size_t count) const {
         bool s0 = idx[first] < nsph;
+        if (count > 1 && idx[first] >= first_solo) return false;
         for (size_t i = first + 1; i < first + count; ++i)
-            if ((idx[i] < nsph) != s0) return false;
+            if ((idx[i] < nsph) != s0 || idx[i] >= first_solo) return false;
         return true;
     }
 
@@ -435,21 +439,26 @@ void for_each_piece(size_t n_pieces, const std::function<void(size_t)>& fn) {
     crew.run(n_pieces, fn);
 }
 
+static void build_bvh_solo(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, size_t first_solo, bool serial);
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out) {
+    build_bvh_solo(boxes, n_spheres, out, SIZE_MAX, false);
+}
+static void build_bvh_solo(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, size_t first_solo, bool serial) {
     out = BvhResult();
     const size_t n = boxes.size();
     if (n == 0) return;
     out.nodes.reserve(n / 2 + 16);
     out.tri_order.reserve(n - n_spheres);
     out.sph_order.reserve(n_spheres);
-    const unsigned T = build_threads();
+    const unsigned T = serial ? 1u : build_threads();
     const bool threaded = T > 1 && n >= 200000;
     Team crew(threaded ? T : 1u);
     Shared sh(boxes, n_spheres, crew);
+    sh.first_solo = first_solo;
     Builder B(sh, out);
     Box bounds;
     // Probe: would the whole scene be a single leaf?  Then wrap it so that node 0 always exists.
-    bool single = n == 1 || (n <= (size_t)RT_LEAF_MAX && B.homogeneous(0, n));
+    bool single = (n == 1 && first_solo == SIZE_MAX) || (n > 1 && n <= (size_t)RT_LEAF_MAX && B.homogeneous(0, n));
     if (single) {
         Box b;
         for (size_t i = 0; i < n; ++i) b.grow(boxes[i].lo, boxes[i].hi);
@@ -535,6 +544,122 @@ void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& o
         }
         nd.left = root;
         nd.right = REF_EMPTY;
+    }
+}
+
+// Two-level build.  group_of[p] > 0 puts primitive p (a triangle) into group group_of[p] (1 .. n_groups): every group
+// gets a tree of its own, and the top of the final tree is built over the loose primitives and ONE box per group, so no
+// split of the upper levels ever cuts through a group and no node mixes a group's triangles with anything else.  The result
+// is an ordinary BvhResult: the groups' trees are stitched in where the top tree has their boxes.
+void build_bvh_grouped(const std::vector<PrimBox>& boxes, size_t n_spheres, const std::vector<uint32_t>& group_of, uint32_t n_groups,
+                       BvhResult& out) {
+    const size_t n = boxes.size();
+    if (!n_groups || group_of.size() != n) { build_bvh(boxes, n_spheres, out); return; }
+    // ---- members of every group (original triangle indices, ascending) and the loose items
+    std::vector<uint32_t> g_start(n_groups + 2, 0);
+    for (size_t p = n_spheres; p < n; ++p) g_start[group_of[p] + 1]++;
+    for (uint32_t g = 0; g <= n_groups; ++g) g_start[g + 1] += g_start[g];           // group g owns members[g_start[g] .. g_start[g+1])
+    std::vector<uint32_t> members(n - n_spheres), fill(g_start.begin(), g_start.end() - 1);
+    for (size_t p = n_spheres; p < n; ++p) members[fill[group_of[p]]++] = (uint32_t)p;
+    const size_t n_loose_tri = g_start[1] - g_start[0];
+    // ---- the groups' trees, side by side
+    std::vector<BvhResult> sub(n_groups + 1);
+    std::vector<PrimBox> gbox(n_groups + 1);
+    {
+        Team crew(build_threads());
+        crew.run(n_groups, [&](size_t k) {
+            const uint32_t g = (uint32_t)k + 1;
+            const size_t m = g_start[g + 1] - g_start[g];
+            std::vector<PrimBox> local(m);
+            PrimBox b;
+            for (int c = 0; c < 3; ++c) { b.lo[c] = INF; b.hi[c] = -INF; }
+            for (size_t i = 0; i < m; ++i) {
+                local[i] = boxes[members[g_start[g] + i]];
+                for (int c = 0; c < 3; ++c) { b.lo[c] = std::min(b.lo[c], local[i].lo[c]); b.hi[c] = std::max(b.hi[c], local[i].hi[c]); }
+            }
+            gbox[g] = b;
+            build_bvh_solo(local, 0, sub[g], SIZE_MAX, true);
+            for (uint32_t& t : sub[g].tri_order) t = members[g_start[g] + t] - (uint32_t)n_spheres;      // back to the caller's triangle index
+        });
+    }
+    // ---- the top tree: spheres, loose triangles, then one solo item per group
+    std::vector<PrimBox> items(n_spheres + n_loose_tri + n_groups);
+    for (size_t i = 0; i < n_spheres; ++i) items[i] = boxes[i];
+    for (size_t i = 0; i < n_loose_tri; ++i) items[n_spheres + i] = boxes[members[g_start[0] + i]];
+    for (uint32_t g = 1; g <= n_groups; ++g) items[n_spheres + n_loose_tri + g - 1] = gbox[g];
+    BvhResult top;
+    build_bvh_solo(items, n_spheres, top, n_spheres + n_loose_tri, false);
+    // ---- stitch.  Final triangle order: the top tree's loose triangles in its leaf order, then group after group.
+    out = BvhResult();
+    out.sph_order = top.sph_order;
+    std::vector<uint32_t> new_pos(top.tri_order.size(), 0xFFFFFFFFu);
+    out.tri_order.reserve(n - n_spheres);
+    for (size_t k = 0; k < top.tri_order.size(); ++k) {
+        if (top.tri_order[k] < n_loose_tri) {
+            new_pos[k] = (uint32_t)out.tri_order.size();
+            out.tri_order.push_back(members[g_start[0] + top.tri_order[k]] - (uint32_t)n_spheres);
+        }
+    }
+    std::vector<uint32_t> node_base(n_groups + 2, 0), tri_base(n_groups + 2, 0);
+    node_base[1] = (uint32_t)top.nodes.size();
+    tri_base[1] = (uint32_t)out.tri_order.size();
+    for (uint32_t g = 1; g <= n_groups; ++g) {
+        node_base[g + 1] = node_base[g] + (uint32_t)sub[g].nodes.size();
+        tri_base[g + 1] = tri_base[g] + (uint32_t)sub[g].tri_order.size();
+    }
+    out.nodes.resize(node_base[n_groups + 1]);
+    out.tri_order.resize(tri_base[n_groups + 1]);
+    out.max_leaf = top.max_leaf;
+    // the top tree's references: loose leaves move to their new positions, a group's solo leaf becomes its tree's root
+    std::vector<uint32_t> group_depth(n_groups + 1, 0);
+    {
+        struct It { uint32_t node, depth; };
+        std::vector<It> st;
+        st.push_back({0u, 0u});
+        auto fix = [&](uint32_t ref, uint32_t depth) -> uint32_t {
+            if (ref == REF_EMPTY || !(ref & REF_LEAF)) { if (ref != REF_EMPTY) st.push_back({ref, depth}); return ref; }
+            if (ref & REF_SPHERE) return ref;
+            const uint32_t first = ref & REF_FIRST_MASK;
+            const uint32_t item = top.tri_order[first];
+            if (item >= n_loose_tri) {                                   // (alone in its leaf by construction)
+                const uint32_t g = item - (uint32_t)n_loose_tri + 1;
+                group_depth[g] = depth;
+                return node_base[g];
+            }
+            return (ref & ~REF_FIRST_MASK) | new_pos[first];
+        };
+        while (!st.empty()) {
+            const It it = st.back();
+            st.pop_back();
+            Node64 nd = top.nodes[it.node];
+            nd.left = fix(nd.left, it.depth + 1);
+            nd.right = fix(nd.right, it.depth + 1);
+            out.nodes[it.node] = nd;
+        }
+    }
+    out.depth = top.depth;
+    {
+        Team crew(build_threads());
+        crew.run(n_groups, [&](size_t k) {
+            const uint32_t g = (uint32_t)k + 1;
+            const uint32_t nb = node_base[g], tb = tri_base[g];
+            for (size_t i = 0; i < sub[g].nodes.size(); ++i) {
+                Node64 nd = sub[g].nodes[i];
+                auto fix = [&](uint32_t ref) -> uint32_t {
+                    if (ref == REF_EMPTY) return ref;
+                    return (ref & REF_LEAF) ? ref + tb : ref + nb;
+                };
+                nd.left = fix(nd.left);
+                nd.right = fix(nd.right);
+                out.nodes[nb + i] = nd;
+            }
+            std::copy(sub[g].tri_order.begin(), sub[g].tri_order.end(), out.tri_order.begin() + tb);
+        });
+    }
+    for (uint32_t g = 1; g <= n_groups; ++g) {
+        // a group's root node sits where the solo leaf's reference sat (depth d): its own references are d deeper
+        out.depth = std::max(out.depth, group_depth[g] + sub[g].depth);
+        out.max_leaf = std::max(out.max_leaf, sub[g].max_leaf);
     }
 }
 

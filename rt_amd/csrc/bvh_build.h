@@ -32,6 +32,12 @@ void for_each_piece(size_t n_pieces, const std::function<void(size_t)>& fn);
 // boxes: first n_spheres entries are spheres, the rest triangles (the caller's primitive order).
 void build_bvh(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out);
 
+// Two-level build for scenes made of many separate objects: group_of[p] (one entry per primitive; 0 = loose, g > 0 =
+// triangle p belongs to group g of 1 .. n_groups, each of at least 8 triangles) gives every group a tree of its own under a
+// top tree over the loose primitives and the groups' boxes.  The result has the layout of build_bvh's.
+void build_bvh_grouped(const std::vector<PrimBox>& boxes, size_t n_spheres, const std::vector<uint32_t>& group_of, uint32_t n_groups,
+                       BvhResult& out);
+
 // The same result from the device (bvh_gpu.hip: Morton order, Karras radix tree, bottom-up fit; leaf collapse and
 // depth-first renumbering on the host).  Returns 0 = ok; > 0 = not applicable (tiny scene, tree deeper than
 // BVH_MAX_DEPTH): use build_bvh; < 0 = error, message in err.  Needs a current HIP device.

@@ -93,6 +93,7 @@ struct Tuning {
     std::string builder;          // RT_HIP_BUILDER=lbvh: the device builder (tests/test_gpu_parity.py: both builders, same hits)
     std::string node_boxes;       // RT_HIP_NODE_BOXES=f64|f32|q16|w4|w4f|w8: force a node format (test_gpu_parity.py: every format)
     int all_lanes_load = -1;      // RT_HIP_ALL_LANES_LOAD=0|1: every-lane-fetches walk off / on (default: by scene size)
+    int groups = -1;              // RT_HIP_GROUPS=0|1: two-level build over the scene's separate meshes off / on (default: by scene)
     int bvh8 = -1;                // RT_HIP_BVH8=0|1: the BVH8 as the default format of the per-lane walk off / on (default: by scene size)
     // per call
     bool no_packet = false;       // RT_HIP_NO_PACKET: camera rays through the per-lane walk (test_gpu_configs.py: kernel variants)
@@ -118,6 +119,7 @@ Tuning read_tuning() {
     t.builder = str("RT_HIP_BUILDER");
     t.node_boxes = str("RT_HIP_NODE_BOXES");
     t.all_lanes_load = set("RT_HIP_ALL_LANES_LOAD") ? (num("RT_HIP_ALL_LANES_LOAD", 0) != 0 ? 1 : 0) : -1;
+    t.groups = set("RT_HIP_GROUPS") ? (num("RT_HIP_GROUPS", 0) != 0 ? 1 : 0) : -1;
     t.bvh8 = set("RT_HIP_BVH8") ? (num("RT_HIP_BVH8", 0) != 0 ? 1 : 0) : -1;
     t.no_packet = set("RT_HIP_NO_PACKET");
     t.no_fuse = set("RT_HIP_NO_FUSE");
@@ -328,10 +330,67 @@ void sphere_texture_rotation(const double f[3], double r[9]) {
         for (int j = 0; j < 3; ++j) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
 }
 
+// Scenes whose build looks for separate meshes first (RT_HIP_GROUPS=0|1 overrides)
+bool default_groups(size_t n_triangles) {
+    (void)n_triangles;
+    return false;
+}
+
 // Scenes that walk the BVH8 by default (RT_HIP_NODE_BOXES=w8 / w4 / ... overrides either way)
 bool default_bvh8(size_t n_prims) {
     (void)n_prims;
     return false;
+}
+
+// Connected components of the triangle soup (triangles that share a vertex position, bit for bit): the separate objects a
+// scene is made of — what the reference's mesh_scene / from_gltf loads one by one (src/hittable.rs:497-633).  Components of
+// min_size .. max_size triangles become groups 1 .. n for build_bvh_grouped; everything else (the terrain, loose
+// triangles) stays 0.  group_of has one entry per primitive (spheres first).  Returns the number of groups.
+uint32_t find_mesh_groups(const rt_triangle* tris, size_t n_tris, size_t n_spheres, size_t min_size, size_t max_size,
+                          std::vector<uint32_t>& group_of, size_t& grouped_tris) {
+    group_of.assign(n_spheres + n_tris, 0u);
+    grouped_tris = 0;
+    if (n_tris < 2 * min_size || n_tris >= (size_t(1) << 30)) return 0;
+    std::vector<uint32_t> parent(n_tris);
+    for (size_t i = 0; i < n_tris; ++i) parent[i] = (uint32_t)i;
+    auto find = [&](uint32_t x) {
+        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+        return x;
+    };
+    size_t cap = 1;
+    while (cap < 6 * n_tris) cap <<= 1;
+    std::vector<uint32_t> table(cap, 0xFFFFFFFFu);          // corner index (3 * triangle + k) of the first vertex with that position
+    auto corner = [&](uint32_t c) -> const double* { const rt_triangle& t = tris[c / 3]; return c % 3 == 0 ? t.a : c % 3 == 1 ? t.b : t.c; };
+    for (size_t i = 0; i < n_tris; ++i)
+        for (uint32_t k = 0; k < 3; ++k) {
+            const uint32_t c = (uint32_t)(3 * i + k);
+            const double* v = corner(c);
+            uint64_t b[3];
+            memcpy(b, v, 24);
+            for (uint64_t& w : b) if (w == 0x8000000000000000ull) w = 0;      // -0.0 and +0.0 are the same place
+            uint64_t h = b[0] * 0x9E3779B97F4A7C15ull;
+            h = (h ^ (h >> 29)) + b[1] * 0xBF58476D1CE4E5B9ull;
+            h = (h ^ (h >> 32)) + b[2] * 0x94D049BB133111EBull;
+            h ^= h >> 31;
+            for (size_t slot = h & (cap - 1);; slot = (slot + 1) & (cap - 1)) {
+                const uint32_t o = table[slot];
+                if (o == 0xFFFFFFFFu) { table[slot] = c; break; }
+                const double* w = corner(o);
+                if (w[0] == v[0] && w[1] == v[1] && w[2] == v[2]) {
+                    const uint32_t ra = find((uint32_t)i), rb = find(o / 3);
+                    if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+                    break;
+                }
+            }
+        }
+    std::vector<uint32_t> size(n_tris, 0), id(n_tris, 0);
+    for (size_t i = 0; i < n_tris; ++i) size[find((uint32_t)i)]++;
+    uint32_t n_groups = 0;
+    for (size_t i = 0; i < n_tris; ++i)
+        if (size[i] >= min_size && size[i] <= max_size) { id[i] = ++n_groups; grouped_tris += size[i]; }      // (roots only have a size)
+    if (!n_groups) return 0;
+    for (size_t i = 0; i < n_tris; ++i) group_of[n_spheres + i] = id[find((uint32_t)i)];
+    return n_groups;
 }
 
 bool finite3(const double* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
@@ -978,7 +1037,18 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             built = brc == 0;
         }
         sc->device_built = built;
-        if (!built) build_bvh(boxes, n_spheres, bvh);
+        if (!built) {
+            // Scenes made of many separate meshes (RT_HIP_GROUPS=1, or by default from GROUPS_MIN_TRIS triangles on when a
+            // fifth of them sit in such meshes): a tree per mesh under a top tree over the meshes' boxes.
+            std::vector<uint32_t> group_of;
+            size_t grouped = 0;
+            uint32_t n_groups = 0;
+            const bool want = sc->tune.groups >= 0 ? sc->tune.groups != 0 : default_groups(n_triangles);
+            if (want) n_groups = find_mesh_groups(triangles, n_triangles, n_spheres, 16, 65536, group_of, grouped);
+            if (n_groups && (sc->tune.groups > 0 || grouped * 5 >= n_triangles)) build_bvh_grouped(boxes, n_spheres, group_of, n_groups, bvh);
+            else build_bvh(boxes, n_spheres, bvh);
+            if (sc->tune.debug) fprintf(stderr, "[rt_hip] builder: %u mesh groups holding %zu of %zu triangles\n", n_groups, grouped, n_triangles);
+        }
         if (bvh.depth > (uint32_t)BVH_MAX_DEPTH)
             return fail(RT_ERR_LIMIT, "internal: BVH depth %u exceeds the traversal stack (%d)", bvh.depth, BVH_MAX_DEPTH);
         if (bvh.tri_order.size() != n_triangles || bvh.sph_order.size() != n_spheres)

@@ -222,6 +222,39 @@ int main() {
         std::vector<PrimBox> b(5000, random_boxes(1)[0]);
         check_tree("5000 coincident", b, 100);
     }
+    {   // two-level build: clusters of boxes as groups, the rest loose; the stitched tree is an ordinary one
+        std::vector<PrimBox> b = random_boxes(60000);
+        const size_t ns = 300;
+        std::vector<uint32_t> group_of(b.size(), 0);
+        uint32_t n_groups = 0;
+        for (size_t i = ns + 5000; i + 700 <= b.size(); i += 700) {
+            ++n_groups;
+            const size_t m = n_groups % 7 == 0 ? 3 : 40 + (n_groups * 37) % 600;          // a few tiny groups among them
+            double c[3] = {U(rng), U(rng), U(rng)};
+            for (size_t k = 0; k < m; ++k) {
+                group_of[i + k] = n_groups;
+                for (int a = 0; a < 3; ++a) { const double e = 0.05 * S(rng), x = c[a] + 0.02 * U(rng); b[i + k].lo[a] = x - e; b[i + k].hi[a] = x + e; }
+            }
+        }
+        BvhResult r;
+        build_bvh_grouped(b, ns, group_of, n_groups, r);
+        std::vector<int> seen(b.size(), 0);
+        uint32_t max_depth = 0;
+        walk(r, b, ns, 0, 0, seen, max_depth);
+        size_t bad = 0;
+        for (int s_ : seen) bad += s_ != 1;
+        CHECK(bad == 0, "grouped build: %zu primitives not in exactly one leaf", bad);
+        CHECK(max_depth == r.depth && r.depth <= (uint32_t)BVH_MAX_DEPTH, "grouped build: depth %u (recorded %u)", max_depth, r.depth);
+        CHECK(r.tri_order.size() == b.size() - ns && r.sph_order.size() == ns, "grouped build: order sizes");
+        check_wide8("grouped 60k", r, b, ns);
+        printf("%-28s n=%8zu nodes=%8zu depth=%2u groups=%u\n", "grouped 60k", b.size(), r.nodes.size(), r.depth, n_groups);
+        BvhResult r1;
+        setenv("RT_HIP_BUILD_THREADS", "1", 1);
+        build_bvh_grouped(b, ns, group_of, n_groups, r1);
+        unsetenv("RT_HIP_BUILD_THREADS");
+        CHECK(r1.tri_order == r.tri_order && r1.nodes.size() == r.nodes.size() &&
+              memcmp(r1.nodes.data(), r.nodes.data(), r.nodes.size() * sizeof(Node64)) == 0, "grouped build depends on the thread count");
+    }
     const std::vector<PrimBox> big = random_boxes(300000);
     setenv("RT_HIP_BUILD_THREADS", "4", 1);
     check_tree("mixed 300k (4 threads)", big, 20000);

@@ -202,8 +202,10 @@ def test_walk_kernel_modes_give_the_same_hits_and_image(monkeypatch, textured, o
     kw = dict(spp=6, seed=3, max_paths_in_flight=160 * 90 * 2, with_stats=True)
     base, st0 = cam.render_image(world, **kw)
     assert_hits_equal(world.hit(rays), want)
+    # ... and two other trees over the same primitives: the two-level build (a tree per separate mesh — the scene's
+    # instances — under a top tree over their boxes: RT_HIP_GROUPS) and the BVH8 with its own walk kernel
     for var, val in (("RT_HIP_ALL_LANES_LOAD", "0"), ("RT_HIP_ALL_LANES_LOAD", "1"), ("RT_HIP_OVF_LDS_ROWS", "4"),
-                     ("RT_HIP_OVF_LDS_ROWS", "12")):
+                     ("RT_HIP_OVF_LDS_ROWS", "12"), ("RT_HIP_GROUPS", "1"), ("RT_HIP_NODE_BOXES", "w8")):
         monkeypatch.setenv(var, val)
         w2 = World.build(desc)
         assert_hits_equal(w2.hit(rays), want)
