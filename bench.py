@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+VALU_CEILING = 0.85      # what a pure VALU loop reads on the roofline's figure (tools/micro/valu_rate2.hip under the same counters)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 
 
@@ -435,13 +436,16 @@ def main():
             # out of memory bandwidth: its scene is served by L2 + Infinity Cache (roofline_hbm_nominal below prices the
             # ALGORITHMIC bytes against the HBM peak and overshoots what any memory level delivers), and rocprofv3's
             # SQ_ACTIVE_INST_VALU says the vector ALUs are busy `achieved` of every SIMD-cycle at ~3 resident waves per SIMD
-            # (a wave64 VALU instruction occupies its SIMD for 4 cycles, f64 and f32 alike on gfx950:
-            # profiles/r03_b_valu_issue_rates.txt).  achieved / frac come from the committed PMC summary named in `source`
+            # (a wave64 VALU instruction occupies its SIMD for 4-5 cycles, f64 and f32 alike on gfx950, and a loop of nothing
+            # but independent VALU instructions, four waves per SIMD, reads 0.80-0.85 on this same figure, 0.95 for the
+            # quarter-rate operations: `measured_ceiling`, profiles/r03_g_instruction_costs.txt).  achieved / frac come from
+            # the committed PMC summary named in `source`
             # (separate --pmc passes of this same command; counters cannot be read inside the timed run); the launch
             # duration, segments and rays/s beside them are measured live here with HIP events on the kernel's stream.
             "roofline": {"bound": "valu_issue", "achieved": k_valu, "peak": 1.0,
                          "unit": "VALU-active wave-cycles per SIMD-cycle (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024))",
                          "frac": k_valu, "traffic": None, "source": pmc_src,
+                         "measured_ceiling": VALU_CEILING, "frac_of_measured_ceiling": (k_valu / VALU_CEILING) if k_valu else None,
                          "valu_active_per_simd_cycle": valu,
                          "valu_lane_utilisation": pmc_walk.get("valu_lane_utilisation"),
                          "valu_instructions_per_launch": insts,

@@ -41,7 +41,8 @@ void build_bvh_grouped(const std::vector<PrimBox>& boxes, size_t n_spheres, cons
 // The same result from the device (bvh_gpu.hip: Morton order, Karras radix tree, bottom-up fit; leaf collapse and
 // depth-first renumbering on the host).  Returns 0 = ok; > 0 = not applicable (tiny scene, tree deeper than
 // BVH_MAX_DEPTH): use build_bvh; < 0 = error, message in err.  Needs a current HIP device.
-int build_bvh_device(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, std::string& err);
+// phase_s (optional): seconds spent in {upload + kernels + download, host finish}
+int build_bvh_device(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, std::string& err, double* phase_s = nullptr);
 
 // f32 copy of the nodes with boxes rounded outward.
 void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out);

@@ -15,6 +15,7 @@
 // gives the same closest hits; the parity tests run on both builders.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string.h>
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(GB) void k_fit(const PrimBox* boxes, const uint32_t
 
 }  // namespace
 
-int build_bvh_device(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, std::string& err) {
+int build_bvh_device(const std::vector<PrimBox>& boxes, size_t n_spheres, BvhResult& out, std::string& err, double* phase_s) {
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_start = clk::now();
     out = BvhResult();
     const size_t n = boxes.size();
     if (n < 64 || n >= (size_t(1) << 28)) return 1;        // tiny scenes: the host builder (single-leaf cases live there)
@@ -217,6 +220,7 @@ fail:
     (void)hipFree(d_left); (void)hipFree(d_right); (void)hipFree(d_first); (void)hipFree(d_pi); (void)hipFree(d_pl);
     (void)hipFree(d_arr); (void)hipFree(d_sub); (void)hipFree(d_nodes); (void)hipFree(d_tmp);
     if (rc) return rc;
+    const clk::time_point t_device = clk::now();
 
     // ---- host finish: leaf order = sorted order per kind; collapse; depth-first renumbering
     std::vector<uint32_t> rank(n + 1);                     // primitives of the same kind before sorted position p
@@ -267,6 +271,10 @@ fail:
         if (ir) stack.push_back({r, nr, it.depth + 1});
         if (il) stack.push_back({l, nl, it.depth + 1});
         out.nodes[it.new_index] = nd;
+    }
+    if (phase_s) {
+        phase_s[0] = std::chrono::duration<double>(t_device - t_start).count();
+        phase_s[1] = std::chrono::duration<double>(clk::now() - t_device).count();
     }
     if (out.depth > (uint32_t)BVH_MAX_DEPTH) return 2;       // deeper than the traversal stacks: the caller falls back
     return 0;

@@ -1032,8 +1032,10 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         bool built = false;
         if (sc->tune.builder == "lbvh") {
             std::string berr;
-            const int brc = build_bvh_device(boxes, n_spheres, bvh, berr);
+            double phase_s[2] = {0.0, 0.0};
+            const int brc = build_bvh_device(boxes, n_spheres, bvh, berr, phase_s);
             if (brc < 0) return fail(RT_ERR_HIP, "device BVH build: %s", berr.c_str());
+            if (sc->tune.debug) fprintf(stderr, "[rt_hip] device builder: bounds %.3f s, upload + kernels + download %.3f s, host finish %.3f s\n", now_s() - tb0 - phase_s[0] - phase_s[1], phase_s[0], phase_s[1]);
             built = brc == 0;
         }
         sc->device_built = built;
@@ -1055,6 +1057,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
             return fail(RT_ERR_INVALID, "internal: BVH lost primitives");
         boxes.clear();
         boxes.shrink_to_fit();
+        const double tb_bvh = now_s();
 
         // ---- flatten
         std::vector<TriGeom> tg(n_triangles);
@@ -1308,6 +1311,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_triangl
         }
         HIPCHK(hipDeviceSynchronize());
         const double tb2 = now_s();
+        if (sc->tune.debug)
+            fprintf(stderr, "[rt_hip] scene creation: bounds + BVH %.3f s, flatten %.3f s, node formats + upload %.3f s\n", tb_bvh - tb0, tb1 - tb_bvh, tb2 - tb1);
         {   // The allocation-free entry point must not be the first to run its kernels on this device: the first launch of a
             // kernel loads its code object and the first launch of a walk kernel asks the runtime for its occupancy
             // (LaunchCtx::walk_slots), and either may allocate.  One ray through the same three launches, here, where

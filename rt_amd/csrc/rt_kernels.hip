@@ -586,6 +586,17 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
                                                                        HitBuf hb, unsigned long long* counters, WalkShade sh) {
     walk_body<BoxT, WIDTH, STATS, false, MODE>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
+// k_walk5: the same kernel held to 96 VGPRs, i.e. five waves per SIMD instead of four.  The BVH4 / Box16 instances without
+// the overflow stack fit into 96 registers without a spill (the overflow instance spills three and loses 20 % of a frame: a
+// scratch reload in the loop waits for every load in flight), and a fifth walk wave per SIMD is worth 1.5-2 % of a frame on
+// the scenes that live in the caches — although five of its waves leave no registers and no LDS for another pass's kernel.
+// The launcher picks it (launch_walk_k: FIVE).
+template <class BoxT, int WIDTH, bool STATS, int MODE>
+__global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(TRACE_BLOCK) void k_walk5(DScene S, RayQueue q, QueueGeom qg, double t_min,
+                                                                                                    double t_max, HitBuf hb, unsigned long long* counters,
+                                                                                                    WalkShade sh) {
+    walk_body<BoxT, WIDTH, STATS, false, MODE>(S, q, qg, t_min, t_max, hb, counters, sh);
+}
 #ifdef RT_TAIL_WAVES
 #define RT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(RT_TAIL_WAVES, RT_TAIL_WAVES)))
 #else
@@ -1433,7 +1444,12 @@ static void launch_walk_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const Que
     // of stack sizes occur: the answers are kept with the scene (one device), filled under the device's mutex
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
     constexpr bool OVF = MODE == WALK_OVF;
-    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
+    constexpr bool FIVE = !SHADE && !STATS && WIDTH == 4 && MODE != WALK_OVF && std::is_same<BoxT, Box16>::value;      // (k_walk5)
+    auto kernel = [] {
+        if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>;
+        else if constexpr (FIVE) return k_walk5<BoxT, WIDTH, STATS, MODE>;
+        else return k_walk<BoxT, WIDTH, STATS, MODE>;
+    }();
     unsigned& cached = ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
     if (!cached) cached = resident_waves(kernel, lds);
     const unsigned chunks = (n_upper + 63u) / 64u;

@@ -12,6 +12,25 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from rt_amd import World, scenes  # noqa: E402
 
+
+def build_logged(desc):
+    """World.build with the library's stderr lines captured (it writes to fd 2 directly)."""
+    import tempfile
+    sys.stderr.flush()
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        keep = os.dup(2)
+        os.dup2(tmp.fileno(), 2)
+        os.environ["RT_HIP_DEBUG_UTIL"] = "1"    # the library reports the phases of scene creation on stderr
+        try:
+            world = World.build(desc)
+        finally:
+            del os.environ["RT_HIP_DEBUG_UTIL"]
+            os.dup2(keep, 2)
+            os.close(keep)
+        tmp.seek(0)
+        return world, tmp.read().decode(errors="replace")
+
+
 small = "--small" in sys.argv
 t0 = time.time()
 desc = scenes.textured_scene() if small else scenes.textured_scene(terrain_quads=1414, instances=12500, tex_size=1024)
@@ -26,10 +45,11 @@ for b in ("sah", "lbvh"):
     creates = []
     for rep in range(2):  # the second creation is the one without first-touch effects
         t0 = time.time()
-        world = World.build(desc)
+        world, log = build_logged(desc)
         creates.append(time.time() - t0)
         if rep == 0:
             world.close()
+    phases = [ln.replace("[rt_hip] ", "") for ln in log.splitlines() if "scene creation:" in ln or "device builder:" in ln]
     info = world.info()
     cam.render_image(world, spp=SPP // 2, seed=1)
     t0 = time.time()
@@ -42,8 +62,7 @@ for b in ("sah", "lbvh"):
         "n_nodes": int(info["n_nodes"]), "bvh_depth": int(info["bvh_depth"]), "bvh_width": int(info["bvh_width"]),
         "node_bytes": int(info["node_bytes"]), "device_MB": info["device_bytes"] / 2 ** 20,
         "render_ms": dt * 1e3, "Msamples_per_s": W * H * SPP / dt / 1e6, "Grays_per_s": seg / dt / 1e9,
-        "nodes_per_bounce_segment": float(st["nodes_visited_bounce"]) / max(int(st["bounce_segments"]), 1),
-        "prims_per_bounce_segment": float(st["prims_tested_bounce"]) / max(int(st["bounce_segments"]), 1),
+        "phases": phases,
         "image_mean": float(img.mean())}
     world.close()
     print("[%s done]" % b, file=sys.stderr, flush=True)
