@@ -126,7 +126,7 @@ def pmc_profile(workload):
     def rec(pre):
         return next((v for n, v in sorted(k.items(), key=lambda x: -x[1]["launches"]) if n.startswith(pre)), {})
 
-    walk = rec("k_walk<") or rec("k_walk8<") or rec("k_trace4<")
+    walk = rec("k_walk5<") or rec("k_walk<") or rec("k_walk8<") or rec("k_trace4<")
     for r in (walk, rec("k_trace_packet")):          # summaries written before round 3 carry one (doubled) figure
         if r and "l2_fabric_bytes_per_launch_low" not in r and "fetch_bytes_per_launch_raw" in r:
             r["l2_fabric_bytes_per_launch_low"] = r["fetch_bytes_per_launch_raw"] + r.get("write_bytes_per_launch", 0.0)

@@ -225,6 +225,7 @@ namespace {
 // start of every tracing / rendering entry point, with the device's mutex held
 void refresh_tuning(rt_scene* sc) {
     sc->tune = read_tuning();
+    sc->lctx.debug = sc->tune.debug;
     sc->lctx.refill = !sc->tune.no_refill;
     sc->lctx.refill_slots = (unsigned)sc->tune.refill_slots;
     const int r = sc->tune.ovf_lds_rows;
@@ -618,6 +619,12 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     // (ensure_pipe_streams): with pipe 0 on the caller's stream, whatever other streams the host had made decided whether
     // two pipes shared a queue.
     if ((rc = ensure_pipe_streams(sc, n_pipes))) return rc;
+    // several passes in flight: the 96-register walk (rt_kernels.hip: k_walk5); the other entry points launch one walk at a time
+    struct FiveGuard {
+        LaunchCtx& c;
+        ~FiveGuard() { c.five = false; }
+    } five_guard{sc->lctx};
+    sc->lctx.five = n_pipes > 1;
 
     PassParams pp0;
     pp0.cam = *cam;

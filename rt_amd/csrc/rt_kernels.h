@@ -76,10 +76,13 @@ struct StackOverflow {
 constexpr uint32_t OVF_LDS_ROWS = 32;                // stack rows the overflow-stack kernels keep in LDS
 // What the walk launchers keep per scene (= per device) beyond their arguments; filled and read under the device's mutex.
 struct LaunchCtx {
+    bool debug = false;                  // RT_HIP_DEBUG_UTIL: say on stderr what the occupancy queries answer
     bool refill = true;                  // persistent launches with lane refill (false: one chunk per wave; tests)
     unsigned refill_slots = 0;           // tests: number of persistent waves (0 = what the device holds)
     uint32_t ovf_lds_rows = OVF_LDS_ROWS;    // tests lower it so that small scenes reach the overflow rows
+    bool five = false;                   // several passes in flight: the 96-register walk (k_walk5), set per call by the renderer
     unsigned walk_slots[2][2][5] = {};   // resident waves of the scene's walk kernel by [STATS][SHADE][stack size class]; 0 = not asked yet
+    unsigned walk5_slots[5] = {};        // the same for k_walk5
 };
 uint32_t stack_overflow_rows(const DScene& S, uint32_t lds_rows);       // rows a StackOverflow buffer needs for this scene (0: none)
 void launch_walk(LaunchCtx& ctx, const DScene& S, RayQueue q, const QueueGeom& qg, uint32_t n_upper, double t_min, double t_max, HitBuf hb,

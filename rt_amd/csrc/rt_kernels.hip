@@ -590,7 +590,8 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
 // the overflow stack fit into 96 registers without a spill (the overflow instance spills three and loses 20 % of a frame: a
 // scratch reload in the loop waits for every load in flight), and a fifth walk wave per SIMD is worth 1.5-2 % of a frame on
 // the scenes that live in the caches — although five of its waves leave no registers and no LDS for another pass's kernel.
-// The launcher picks it (launch_walk_k: FIVE).
+// Alone (one pass in flight, rt_trace_closest) it is 8 % SLOWER than k_walk, so the renderer asks for it only when several
+// passes are in flight (LaunchCtx::five).
 template <class BoxT, int WIDTH, bool STATS, int MODE>
 __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(TRACE_BLOCK) void k_walk5(DScene S, RayQueue q, QueueGeom qg, double t_min,
                                                                                                     double t_max, HitBuf hb, unsigned long long* counters,
@@ -1208,7 +1209,12 @@ __device__ __forceinline__ void shade_wave(const DScene& S, const PassParams& pp
     }
     queue_append(alive, wave, lane, qo, wq.shard_cap, out_counts, pid, no, nd, nthr);
 }
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
+#ifdef RT_SHADE_WAVES
+#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#else
+#define RT_SHADE_ATTR
+#endif
+__global__ RT_SHADE_ATTR __launch_bounds__(BLOCK) void k_shade(DScene S, PassParams pp, uint32_t depth, RayQueue qi, QueueGeom qg,
                                                  HitBuf hb, RayQueue qo, uint32_t* out_counts, double* path_radiance, uint32_t* hist) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
@@ -1444,14 +1450,17 @@ static void launch_walk_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const Que
     // of stack sizes occur: the answers are kept with the scene (one device), filled under the device's mutex
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
     constexpr bool OVF = MODE == WALK_OVF;
-    constexpr bool FIVE = !SHADE && !STATS && WIDTH == 4 && MODE != WALK_OVF && std::is_same<BoxT, Box16>::value;      // (k_walk5)
-    auto kernel = [] {
-        if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>;
-        else if constexpr (FIVE) return k_walk5<BoxT, WIDTH, STATS, MODE>;
-        else return k_walk<BoxT, WIDTH, STATS, MODE>;
-    }();
-    unsigned& cached = ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
-    if (!cached) cached = resident_waves(kernel, lds);
+    constexpr bool FIVE_OK = !SHADE && !STATS && WIDTH == 4 && MODE != WALK_OVF && std::is_same<BoxT, Box16>::value;      // (k_walk5)
+    auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
+    unsigned* slot_cache = &ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
+    if constexpr (FIVE_OK) {
+        if (ctx.five) { kernel = k_walk5<BoxT, WIDTH, STATS, MODE>; slot_cache = &ctx.walk5_slots[ci]; }
+    }
+    unsigned& cached = *slot_cache;
+    if (!cached) {
+        cached = resident_waves(kernel, lds);
+        if (ctx.debug) fprintf(stderr, "[rt_hip] walk kernel (stats %d, shade %d, mode %d, 96 registers %d): %zu B of LDS per wave, %u resident waves\n", (int)STATS, (int)SHADE, MODE, (int)(FIVE_OK && ctx.five), lds, cached);
+    }
     const unsigned chunks = (n_upper + 63u) / 64u;
     // persistent (one wave per hardware slot, lanes refilled); never more waves than the queue can have chunks.
     unsigned hw = cached;
