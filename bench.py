@@ -269,6 +269,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if STANDIN:
         return standin_main(args, rank, world)
+    # stdout carries ONE JSON line and nothing else: whatever libraries print there (RCCL writes a version banner to stdout
+    # when it initialises) goes to stderr from here on, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -493,7 +498,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
