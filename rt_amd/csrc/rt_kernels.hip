@@ -325,22 +325,28 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
     // select of ADDRESSES inside the argument block plus a per-lane load — one more dependent memory round trip per step)
     constexpr bool OVF = MODE == WALK_OVF;
     extern __shared__ uint32_t stack_mem[];
-    uint32_t (*stack)[TRACE_BLOCK] = reinterpret_cast<uint32_t (*)[TRACE_BLOCK]>(stack_mem);
-    const uint32_t tid = threadIdx.x;
+    // The stack pointer is the BYTE ADDRESS of the lane's next free entry in LDS, spa = 256 * entries + 4 * lane: a push is a
+    // store at spa, the lane's number rides in its low byte, and neither threadIdx.x nor 4 * threadIdx.x has to stay in a
+    // register across the loop (they were the two values the 96-register build of the overflow instance spilled, and reloaded
+    // from scratch inside the loop).  An idle lane's spa is 4 * lane: a ray that starts has nothing to reset.
+#define RT_LDS_AT(addr) (*reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stack_mem) + (addr)))
+#define RT_ROWS() (spa >> 8)
     // (the overflow address is formed where it is used: a per-lane pointer kept across the loop would cost the kernel the
     // two registers that decide whether a camera-ray or shading wave still fits next to four of its waves on a SIMD)
-#define RT_OVF_AT(row) sh.stack_ovf[((uint32_t)(row) * gridDim.x + blockIdx.x) * (uint32_t)TRACE_BLOCK + tid]      // (< 2^32: the launcher checks)
+#define RT_OVF_AT(row) sh.stack_ovf[((uint32_t)(row) * gridDim.x + blockIdx.x) * (uint32_t)TRACE_BLOCK + ((spa & 255u) >> 2)]      // (< 2^32: the launcher checks)
     // `deep` (wave-uniform, set once per step): some lane's stack may reach the overflow rows in this step; otherwise the
     // pushes and pops are the plain LDS ones — one compare and one scalar branch per step instead of a check per access
     const uint32_t lds_rows = sh.ovf_lds_rows;      // (a scalar; only the OVF instances read it)
-#define RT_PUSH(v) { if (!OVF || !deep || (uint32_t)sp < lds_rows) stack[sp][tid] = (v); else RT_OVF_AT((uint32_t)sp - lds_rows) = (v); ++sp; }
-#define RT_POP() (--sp, (!OVF || !deep || (uint32_t)sp < lds_rows) ? stack[sp][tid] : RT_OVF_AT((uint32_t)sp - lds_rows))
+#define RT_PUSH(v) { if (!OVF || !deep || RT_ROWS() < lds_rows) RT_LDS_AT(spa) = (v); else RT_OVF_AT(RT_ROWS() - lds_rows) = (v); spa += 256u; }
+#define RT_POP() (spa -= 256u, (!OVF || !deep || RT_ROWS() < lds_rows) ? RT_LDS_AT(spa) : RT_OVF_AT(RT_ROWS() - lds_rows))
+#define RT_ANY() (spa >= 256u)
     // The queue's counts are read once here (size in waves, total) and looked up again per refill through the scalar
     // cache (slot_light): nothing of them stays in a VGPR across the loop — the kernel's register count decides whether
     // a camera-ray or shading wave of another pass still fits next to four of its waves on a SIMD.
     WaveQueue wq;
-    wq.load(qg, tid);
+    wq.load(qg, threadIdx.x);
     if (blockIdx.x == 0) {
+        const uint32_t tid = threadIdx.x;
         uint32_t tot = wq.direct ? 0u : wq.cnt;
         for (int off = 32; off; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
         if (wq.direct) tot = wq.n_direct;
@@ -367,7 +373,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
     double best = t_max;                                              // (barycentrics go to hb when a hit is accepted:
     uint32_t prim = RT_MISS;                                          //  four registers fewer across the loop)
     uint32_t cur = REF_EMPTY;
-    int sp = 0;
+    uint32_t spa = 4u * threadIdx.x;
     uint32_t n_nodes = 0, n_prims = 0, n_iters = 0, n_leaves = 0, n_seg = 0;
 
     for (;;) {
@@ -393,7 +399,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                         o = no; d = nd; thr = nthr; ++depth;
                         rb.init(S, o, d, t_min, t_max);
                         best = t_max; prim = RT_MISS;
-                        cur = S.root; sp = 0;
+                        cur = S.root;      // (its stack is empty: spa is back at 4 * lane)
                     } else {
                         busy = false;
                     }
@@ -423,7 +429,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                     }
                     rb.init(S, o, d, t_min, t_max);
                     best = t_max; prim = RT_MISS;
-                    cur = S.root; sp = 0;
+                    cur = S.root;      // (its stack is empty: spa is back at 4 * lane)
                 }
                 chunk_pos += take;
                 more = chunk_pos < 64u || next_chunk < n_chunks;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             continue;
         }
         if (STATS) ++n_iters;
-        const bool deep = OVF && __ballot((uint32_t)sp + 3u > lds_rows) != 0ull;
+        const bool deep = OVF && __ballot(RT_ROWS() + 3u > lds_rows) != 0ull;
         // One dependent memory round trip per iteration for every lane: a node lane fetches its 64-byte node,
         // a leaf lane ONE primitive of its leaf (80-byte triangle / 64-byte sphere); a leaf of n primitives
         // takes n iterations (the reference keeps count and first, so it is advanced in place).  All loads are
@@ -509,7 +515,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 if (ref[3] != REF_EMPTY) RT_PUSH(ref[3])
                 if (ref[2] != REF_EMPTY) RT_PUSH(ref[2])
                 if (ref[1] != REF_EMPTY) RT_PUSH(ref[1])
-                cur = ref[0] != REF_EMPTY ? ref[0] : (sp ? RT_POP() : REF_EMPTY);
+                cur = ref[0] != REF_EMPTY ? ref[0] : (RT_ANY() ? RT_POP() : REF_EMPTY);
             } else {
                 typename BoxT::Scalar lo_l[3], hi_l[3], lo_r[3], hi_r[3], tl = 0, tr = 0;
                 uint32_t cl, cr;
@@ -525,7 +531,7 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 } else if (hr) {
                     cur = cr;
                 } else {
-                    cur = sp ? RT_POP() : REF_EMPTY;
+                    cur = RT_ANY() ? RT_POP() : REF_EMPTY;
                 }
             }
         }
@@ -550,12 +556,17 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
             // next primitive of the same leaf, or pop
             // (BVH4: references count 16-byte units — a triangle is 5 of them, a sphere 4)
             const uint32_t next_ = W4 ? ((cur & REF_SPHERE) ? (uint32_t)(sizeof(SphGeom) / 16) : (uint32_t)(sizeof(TriGeom) / 16)) : 1u;
-            cur = (cur & 0x30000000u) ? cur - 0x10000000u + next_ : (sp ? RT_POP() : REF_EMPTY);
+            cur = (cur & 0x30000000u) ? cur - 0x10000000u + next_ : (RT_ANY() ? RT_POP() : REF_EMPTY);
         }
     }
 #undef RT_PUSH
 #undef RT_POP
+#undef RT_ANY
+#undef RT_ROWS
+#undef RT_LDS_AT
 #undef RT_OVF_AT
+    // (one wave per workgroup: the lane's number, without keeping threadIdx.x alive across the loop)
+    const uint32_t tid = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (SHADE && counters) {
         unsigned long long sg = n_seg;
         for (int off = 32; off; off >>= 1) sg += __shfl_xor(sg, off);
@@ -1450,7 +1461,7 @@ static void launch_walk_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const Que
     // of stack sizes occur: the answers are kept with the scene (one device), filled under the device's mutex
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
     constexpr bool OVF = MODE == WALK_OVF;
-    constexpr bool FIVE_OK = !SHADE && !STATS && WIDTH == 4 && MODE != WALK_OVF && std::is_same<BoxT, Box16>::value;      // (k_walk5)
+    constexpr bool FIVE_OK = !SHADE && !STATS && WIDTH == 4 && std::is_same<BoxT, Box16>::value;      // (k_walk5)
     auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
     unsigned* slot_cache = &ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
     if constexpr (FIVE_OK) {
