@@ -597,12 +597,13 @@ __global__ RT_T4_ATTR __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_walk
                                                                        HitBuf hb, unsigned long long* counters, WalkShade sh) {
     walk_body<BoxT, WIDTH, STATS, false, MODE>(S, q, qg, t_min, t_max, hb, counters, sh);
 }
-// k_walk5: the same kernel held to 96 VGPRs, i.e. five waves per SIMD instead of four.  The BVH4 / Box16 instances without
-// the overflow stack fit into 96 registers without a spill (the overflow instance spills three and loses 20 % of a frame: a
-// scratch reload in the loop waits for every load in flight), and a fifth walk wave per SIMD is worth 1.5-2 % of a frame on
-// the scenes that live in the caches — although five of its waves leave no registers and no LDS for another pass's kernel.
-// Alone (one pass in flight, rt_trace_closest) it is 8 % SLOWER than k_walk, so the renderer asks for it only when several
-// passes are in flight (LaunchCtx::five).
+// k_walk5: the same kernel held to 96 VGPRs.  The BVH4 / Box16 instances fit into 96 registers without a spill (the
+// overflow-stack instance only since the stack pointer carries the lane number: before, it spilled threadIdx.x and
+// 4 * threadIdx.x and reloaded them from scratch inside the loop, where a reload waits for every load in flight: -20 % of a
+// frame).  With several passes in flight it is worth 1.5-2 % of a frame on the 1 M-triangle scene, 3.6 % on the 5 M and 1.9 %
+// on the 20 M scene: its waves leave more of the register file to the other passes' kernels.  Alone (one pass in flight,
+// rt_trace_closest) it is 8 % SLOWER than k_walk — the 96-register schedule is the worse code, and a fifth resident wave
+// does not make up for it — so the renderer asks for it only when several passes are in flight (LaunchCtx::five).
 template <class BoxT, int WIDTH, bool STATS, int MODE>
 __global__ __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(TRACE_BLOCK) void k_walk5(DScene S, RayQueue q, QueueGeom qg, double t_min,
                                                                                                     double t_max, HitBuf hb, unsigned long long* counters,
