@@ -269,6 +269,28 @@ __device__ __forceinline__ bool tri_test(D3 a, D3 e1, D3 e2, D3 o, D3 d, double 
     return true;
 }
 
+// tri_test with the caller's acceptance code run INSIDE the innermost success path (same operations in the same order).
+// In the per-lane walk `if (tri_test(..., t, u, v)) accept(t, u, v)` left t, u, v undefined on the failing paths; the
+// compiler carried them — and copies of the hit state — in registers across the whole traversal loop and moved them
+// about on every iteration (a dozen v_mov per step).  With the use next to the definition there is nothing to merge.
+template <class OnHit>
+__device__ __forceinline__ void tri_test_do(D3 a, D3 e1, D3 e2, D3 o, D3 d, double lo, double hi, OnHit&& on_hit) {
+    D3 uvec = cross(d, e2);
+    double det = dot(e1, uvec);
+    if (det < F64_EPSILON) return;
+    double inv = 1.0 / det;
+    D3 ao = sub(o, a);
+    double u = dot(ao, uvec) * inv;
+    if (!(0.0 <= u && u <= 1.0)) return;
+    D3 vvec = cross(ao, e1);
+    double v = dot(d, vvec) * inv;
+    if (v < 0.0 || u + v > 1.0) return;
+    double t = dot(e2, vvec) * inv;
+    if (!(lo <= t && t < hi)) return;
+    if (!(t > F64_EPSILON)) return;
+    on_hit(t, u, v);
+}
+
 // Sphere::hit (src/hittable.rs:318-365) up to the NaN-uv rejection, which reduces to
 // !(|z'| <= 1) for the rotated normal's z.
 __device__ __forceinline__ bool sph_test(D3 c, double r, D3 rot2, D3 o, D3 d, double lo, double hi, double& tout) {
@@ -291,6 +313,28 @@ __device__ __forceinline__ bool sph_test(D3 c, double r, D3 rot2, D3 o, D3 d, do
     if (!(fabs(zr) <= 1.0)) return false;
     tout = t;
     return true;
+}
+// (the same with the acceptance code inside the success path: see tri_test_do)
+template <class OnHit>
+__device__ __forceinline__ void sph_test_do(D3 c, double r, D3 rot2, D3 o, D3 d, double lo, double hi, OnHit&& on_hit) {
+    D3 oc = sub(c, o);
+    double a = norm2(d);
+    double h = dot(d, oc);
+    double cc = norm2(oc) - r * r;
+    double disc = h * h - a * cc;
+    if (disc < 0.0) return;
+    double sq = sqrt(disc);
+    double t = (h - sq) / a;
+    if (!(lo <= t && t < hi)) {
+        t = (h + sq) / a;
+        if (!(lo <= t && t < hi)) return;
+    }
+    D3 p = add(scale(d, t), o);
+    D3 n = divs(sub(p, c), r);
+    if (!(dot(d, n) < 0.0)) n = neg(n);
+    double zr = (rot2.x * n.x + rot2.y * n.y) + rot2.z * n.z;
+    if (!(fabs(zr) <= 1.0)) return;
+    on_hit(t);
 }
 
 }  // namespace rt

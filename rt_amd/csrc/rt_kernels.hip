@@ -541,17 +541,16 @@ __device__ __forceinline__ void walk_body(const DScene S, const RayQueue q, cons
                 const D3 ta = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
                 const D3 e1 = mk(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
                 const D3 e2 = mk(mkd(r.x, r.y), mkd(r.z, r.w), mkd(e.x, e.y));
-                double t, u, v;
-                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) {
+                // (acceptance inside the test's success path — tri_test_do: nothing of a failed test lives on)
+                tri_test_do(ta, e1, e2, o, d, t_min, best, [&](double t, double u, double v) {
                     best = t; prim = e.z; rb.nearest(best);
                     hb.bu[slot] = u; hb.bv[slot] = v;
-                }
+                });
             } else {                                                  // SphGeom: c, r, rot2 (7 doubles), prim
                 const D3 sc = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
                 const double sr = mkd(b.z, b.w);
                 const D3 rot2 = mk(mkd(c.x, c.y), mkd(c.z, c.w), mkd(r.x, r.y));
-                double t;
-                if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
+                sph_test_do(sc, sr, rot2, o, d, t_min, best, [&](double t) { best = t; prim = r.z; rb.nearest(best); });
             }
             // next primitive of the same leaf, or pop
             // (BVH4: references count 16-byte units — a triangle is 5 of them, a sphere 4)
@@ -1443,13 +1442,15 @@ void launch_prepare_rays(const rt_ray* rays, const QueueGeom& qg, RayQueue q, hi
     hipLaunchKernelGGL(k_prepare_rays, dim3(grid_for(qg.n_direct)), dim3(BLOCK), 0, s, rays, qg, q);
 }
 // waves the chip holds at once of a kernel (one wave per workgroup) with `lds` bytes of dynamic LDS
+// (max_per_cu: a cap on the waves per CU to count, 0 = none)
 template <class K>
-static unsigned resident_waves(K kernel, size_t lds) {
+static unsigned resident_waves(K kernel, size_t lds, unsigned max_per_cu = 0) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TRACE_BLOCK, lds) != hipSuccess || per_cu < 1)
         return 256u * 8u;
+    if (max_per_cu && (unsigned)per_cu > max_per_cu) per_cu = (int)max_per_cu;
     return (unsigned)pr.multiProcessorCount * (unsigned)per_cu;
 }
 // n_upper: an upper bound of the queue's entries the host knows (the pass size): the kernel reads the real counts itself
@@ -1462,15 +1463,25 @@ static void launch_walk_k(LaunchCtx& ctx, const DScene& S, RayQueue q, const Que
     // of stack sizes occur: the answers are kept with the scene (one device), filled under the device's mutex
     const int ci = stack_entries <= 16 ? 0 : stack_entries <= 24 ? 1 : stack_entries <= 32 ? 2 : stack_entries <= 48 ? 3 : 4;
     constexpr bool OVF = MODE == WALK_OVF;
+#ifdef RT_NO_FIVE      // (A/B builds)
+    constexpr bool FIVE_OK = false;
+#else
     constexpr bool FIVE_OK = !SHADE && !STATS && WIDTH == 4 && std::is_same<BoxT, Box16>::value;      // (k_walk5)
+#endif
     auto kernel = [] { if constexpr (SHADE) return k_walk_shade<BoxT, WIDTH, STATS, MODE>; else return k_walk<BoxT, WIDTH, STATS, MODE>; }();
-    unsigned* slot_cache = &ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
+    // (the answers for "several passes in flight" are kept apart: another kernel, or the same one without the cap below)
+    const bool shared = ctx.five && !SHADE && !STATS;
+    unsigned* slot_cache = shared ? &ctx.walk5_slots[ci] : &ctx.walk_slots[STATS ? 1 : 0][SHADE ? 1 : 0][ci];
     if constexpr (FIVE_OK) {
-        if (ctx.five) { kernel = k_walk5<BoxT, WIDTH, STATS, MODE>; slot_cache = &ctx.walk5_slots[ci]; }
+        if (ctx.five) kernel = k_walk5<BoxT, WIDTH, STATS, MODE>;
     }
     unsigned& cached = *slot_cache;
     if (!cached) {
-        cached = resident_waves(kernel, lds);
+        // A stand-alone walk that has the GPU to itself (one pass in flight, rt_trace_closest) runs best with FOUR waves per
+        // SIMD although its 92 registers admit five: 85.5 against 90.7 ms per frame of the 1 M-triangle scene with one
+        // pass in flight.  With several passes in flight the SIMDs are shared anyway and the full count is asked for.
+        const bool alone = !SHADE && !STATS && !ctx.five;
+        cached = resident_waves(kernel, lds, alone ? 16u : 0u);
         if (ctx.debug) fprintf(stderr, "[rt_hip] walk kernel (stats %d, shade %d, mode %d, 96 registers %d): %zu B of LDS per wave, %u resident waves\n", (int)STATS, (int)SHADE, MODE, (int)(FIVE_OK && ctx.five), lds, cached);
     }
     const unsigned chunks = (n_upper + 63u) / 64u;
