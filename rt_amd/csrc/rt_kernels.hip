@@ -819,17 +819,15 @@ __device__ __forceinline__ void walk8_body(const DScene S, const RayQueue q, con
                 const D3 ta = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
                 const D3 e1 = mk(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
                 const D3 e2 = mk(mkd(r.x, r.y), mkd(r.z, r.w), mkd(e.x, e.y));
-                double t, u, v;
-                if (tri_test(ta, e1, e2, o, d, t_min, best, t, u, v)) {
+                tri_test_do(ta, e1, e2, o, d, t_min, best, [&](double t, double u, double v) {
                     best = t; prim = e.z; rb.nearest(best);
                     hb.bu[slot] = u; hb.bv[slot] = v;
-                }
+                });
             } else {                                                  // SphGeom: c, r, rot2 (7 doubles), prim
                 const D3 sc = mk(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
                 const double sr = mkd(b.z, b.w);
                 const D3 rot2 = mk(mkd(c.x, c.y), mkd(c.z, c.w), mkd(r.x, r.y));
-                double t;
-                if (sph_test(sc, sr, rot2, o, d, t_min, best, t)) { best = t; prim = r.z; rb.nearest(best); }
+                sph_test_do(sc, sr, rot2, o, d, t_min, best, [&](double t) { best = t; prim = r.z; rb.nearest(best); });
             }
         }
         // nothing pending at this node any more: back to the group that was set aside last
@@ -1012,8 +1010,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                     const D3 c = mk(mkd(g[0], g[1]), mkd(g[2], g[3]), mkd(g[4], g[5]));
                     const double r = mkd(g[6], g[7]);
                     const D3 rot2 = mk(mkd(g[8], g[9]), mkd(g[10], g[11]), mkd(g[12], g[13]));
-                    double t;
-                    if (mine && sph_test(c, r, rot2, o, d, t_min, best, t)) { best = t; prim = g[14]; rb.nearest(best); }
+                    if (mine) sph_test_do(c, r, rot2, o, d, t_min, best, [&](double t) { best = t; prim = g[14]; rb.nearest(best); });
                 }
             } else {
                 for (uint32_t k = 0; k < count; ++k) {
@@ -1022,8 +1019,7 @@ __global__ RT_PK_ATTR __launch_bounds__(TRACE_BLOCK) void k_trace_packet(DScene 
                     const D3 a = mk(mkd(g[0], g[1]), mkd(g[2], g[3]), mkd(g[4], g[5]));
                     const D3 e1 = mk(mkd(g[6], g[7]), mkd(g[8], g[9]), mkd(g[10], g[11]));
                     const D3 e2 = mk(mkd(g[12], g[13]), mkd(g[14], g[15]), mkd(g2[0], g2[1]));
-                    double t, u, v;
-                    if (mine && tri_test(a, e1, e2, o, d, t_min, best, t, u, v)) { best = t; prim = g2[2]; bu = u; bv = v; rb.nearest(best); }
+                    if (mine) tri_test_do(a, e1, e2, o, d, t_min, best, [&](double t, double u, double v) { best = t; prim = g2[2]; bu = u; bv = v; rb.nearest(best); });
                 }
             }
         }
