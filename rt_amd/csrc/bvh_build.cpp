@@ -816,10 +816,76 @@ struct Wide {
             ++c;
         }
     }
-    // the children of the BVH4 node that replaces BVH2 node n2: its own two, then the grandchildren with the largest
-    // boxes pulled up until there are four
+    // ---- which BVH2 nodes become BVH4 nodes: the optimal choice for the surface-area cost (sum of the BVH4 nodes' areas:
+    // the leaves are the BVH2's own and cost the same whatever is chosen), by the dynamic programme of Ylitie, Karras and
+    // Laine ("Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017, section 3.1) for width 4.
+    // plan[3 m + (k - 2)], k = 2, 3, 4: how many of the k roots that may stand for BVH2 node m's subtree go to its LEFT
+    // child; 0 (k = 2, 3 only) = m stays one root.
+    const uint8_t* plan = nullptr;
+    static void make_plan(const std::vector<Node64>& in, std::vector<uint8_t>& plan) {
+        const size_t n = in.size();
+        plan.assign(3 * n, 0);
+        std::vector<double> cost(3 * n, 0.0);                    // cost[3 m + (k - 1)]: m's subtree as at most k roots, k = 1..3
+        auto of = [&](uint32_t ref, int k) -> double {          // (a leaf costs the same in every plan: 0)
+            return (ref & REF_LEAF) ? 0.0 : cost[3 * (size_t)ref + (size_t)(std::min(k, 3) - 1)];
+        };
+        for (size_t m = n; m-- > 0;) {                           // children sit behind their parents
+            const Node64& nd = in[m];
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) { lo[k] = nd.lo_l[k]; hi[k] = nd.hi_l[k]; }
+            if (nd.right != REF_EMPTY)
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], nd.lo_r[k]); hi[k] = std::max(hi[k], nd.hi_r[k]); }
+            const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+            const double area_m = x * y + y * z + z * x;
+            double dist[5] = {0, 0, 0, 0, 0};
+            uint8_t arg[5] = {0, 0, 0, 0, 0};
+            for (int k = 2; k <= 4; ++k) {
+                if (nd.right == REF_EMPTY) { dist[k] = of(nd.left, k); arg[k] = (uint8_t)std::min(k, 3); continue; }
+                double best = INFINITY;
+                for (int i = std::max(1, k - 3); i <= std::min(3, k - 1); ++i) {
+                    const double c = of(nd.left, i) + of(nd.right, k - i);
+                    if (c < best) { best = c; arg[k] = (uint8_t)i; }
+                }
+                dist[k] = best;
+            }
+            const double c1 = area_m + dist[4];
+            const double c2 = std::min(c1, dist[2]);
+            const double c3 = std::min(c2, dist[3]);
+            cost[3 * m] = c1; cost[3 * m + 1] = c2; cost[3 * m + 2] = c3;
+            plan[3 * m] = dist[2] < c1 ? arg[2] : 0;
+            plan[3 * m + 1] = dist[3] < c2 ? arg[3] : 0;
+            plan[3 * m + 2] = arg[4];
+        }
+    }
+    // the roots (at most k) that stand for the child `side` of `parent` under the plan
+    void expand(const Node64& parent, bool right_side, int k, Ent* e, int& c) const {
+        Ent x;
+        x.ref = right_side ? parent.right : parent.left;
+        for (int j = 0; j < 3; ++j) { x.lo[j] = right_side ? parent.lo_r[j] : parent.lo_l[j]; x.hi[j] = right_side ? parent.hi_r[j] : parent.hi_l[j]; }
+        while (!(x.ref & REF_LEAF) && k > 1) {
+            const Node64& m = in[x.ref];
+            const int i = plan[3 * (size_t)x.ref + (size_t)(k - 2)];
+            if (i == 0) { --k; continue; }                      // the plan for one root fewer
+            if (m.right == REF_EMPTY) { expand(m, false, i, e, c); return; }
+            expand(m, false, i, e, c);
+            expand(m, true, k - i, e, c);
+            return;
+        }
+        e[c++] = x;
+    }
+    // the children of the BVH4 node that replaces BVH2 node n2
     int collapse(uint32_t n2, Ent* e) const {
         int c = 0;
+#ifndef RT_WIDEN_GREEDY
+        if (plan) {
+            const Node64& nd = in[n2];
+            const int i = plan[3 * (size_t)n2 + 2];
+            expand(nd, false, i, e, c);
+            if (nd.right != REF_EMPTY) expand(nd, true, 4 - i, e, c);
+            return c;
+        }
+#endif
+        // (without a plan: its own two, then the grandchildren with the largest boxes pulled up until there are four)
         children(in[n2], e, c);
         while (c < 4) {
             int best = -1;
@@ -917,6 +983,9 @@ bool widen_any(const std::vector<Node64>& in, const QuantGrid& grid, std::vector
     if (in.empty()) return false;
     std::vector<NodeT> res;
     Wide<NodeT> top{in, grid, res};
+    std::vector<uint8_t> plan;
+    Wide<NodeT>::make_plan(in, plan);
+    top.plan = plan.data();
     const unsigned T = build_threads();
     const int levels = (T > 1 && in.size() >= 100000) ? 4 : 0;
     std::vector<uint32_t> roots;
@@ -937,6 +1006,7 @@ bool widen_any(const std::vector<Node64>& in, const QuantGrid& grid, std::vector
     std::vector<char> bad(roots.size(), 0);
     crew.run(roots.size(), [&](size_t k) {
         Wide<NodeT> w{in, grid, res};
+        w.plan = plan.data();
         uint32_t c = base[k];
         w.emit(roots[k], c);
         bad[k] = (!w.ok || c != base[k] + size[k]) ? 1 : 0;
