@@ -51,8 +51,8 @@ void narrow_nodes(const std::vector<Node64>& in, std::vector<Node32>& out);
 // for the scene: mean surface-area inflation of the leaf boxes above `max_inflation`.
 bool quantize_nodes(const std::vector<Node32>& in, std::vector<Node16>& out, QuantGrid& grid, double max_inflation);
 
-// BVH4 over the same leaves: every node absorbs the grandchildren with the largest boxes until it has
-// four children.  Boxes are quantised outward on `grid` (the one quantize_nodes chose).  stack_need =
+// BVH4 over the same leaves: the BVH2 nodes that become BVH4 nodes are chosen for the least summed node area
+// (dynamic programme, Wide::make_plan).  Boxes are quantised outward on `grid` (the one quantize_nodes chose).  stack_need =
 // entries a near-first traversal that pushes every other hit child can hold at once, worst case.
 // Returns false when a box cannot be represented on the grid.
 bool widen_nodes(const std::vector<Node64>& in, const QuantGrid& grid, std::vector<Node4>& out, uint32_t& stack_need);
