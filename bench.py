@@ -172,7 +172,7 @@ def launch_ranks(args):
     import subprocess
     import threading
     n = args.gpus
-    if not STANDIN:
+    if not STANDIN and not SHARE_GPU:
         have = visible_gpus()
         if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
@@ -216,6 +216,11 @@ def launch_ranks(args):
 # RT_BENCH_STANDIN=1: launcher / partition / reduce self-test on CPU (gloo, a synthetic per-sample "renderer" defined
 # below).  It measures nothing and says so in its JSON line; tests/test_bench_launcher.py drives it at world size 2.
 STANDIN = os.environ.get("RT_BENCH_STANDIN") == "1"
+# RT_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a box with ONE GPU — every rank renders on device 0 with the real
+# kernels, and because RCCL refuses two ranks on one device the process group is gloo with the sum-reduce staged through host
+# memory (rt_amd.distributed.reduce_through_host).  It checks the partition + exchange + launcher with real renders; its
+# JSON line says "rehearsal": its value is N ranks time-slicing one GPU and measures nothing.
+SHARE_GPU = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
 
 
 def standin_main(args, rank, world):
@@ -278,6 +283,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the product path")
+    if SHARE_GPU:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: no GPU {local_rank} (only {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -286,7 +293,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if SHARE_GPU:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if SHARE_GPU else "cuda"        # where the small tensors of the timing collectives live
 
     # RT_BENCH_EXTRA_STREAMS=<n> (A/B only): n used streams in the process before the library makes its own, as a host with
     # its own copy / collective streams would have; the library's stream set-up must make the frame rate independent of n
@@ -313,7 +324,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from rt_amd.distributed import hip_render_sum, hip_resolve, render_distributed
+    from rt_amd.distributed import hip_render_sum, hip_resolve, reduce_through_host, render_distributed
 
     # With more than one rank the exchange step of a frame (RCCL sum-reduce over xGMI + rank 0's resolve) is queued on a
     # side stream, so the next frame's kernels do not wait for the collective: two sum buffers alternate, an event per
@@ -335,7 +346,7 @@ def main():
             torch.cuda.current_stream().wait_event(exchanged[b])      # the frame before last has left this buffer
         mean, st = render_distributed(render_sum, sums[b], spp_override or spp, seed=2024,
                                       resolve=lambda s, total: hip_resolve(s, total, local_rank), side_stream=side,
-                                      scaling=args.scaling)
+                                      scaling=args.scaling, reduce=reduce_through_host if SHARE_GPU else None)
         if side is not None:
             exchanged[b] = torch.cuda.Event()
             exchanged[b].record(side)
@@ -350,11 +361,11 @@ def main():
     stats = [st_ for st_ in (step() for _ in range(args.steps)) if st_ is not None]      # (None: a rank beyond the sample count)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    seg = torch.tensor([float(sum(int(s["ray_segments"]) for s in stats))], dtype=torch.float64, device="cuda")
+    seg = torch.tensor([float(sum(int(s["ray_segments"]) for s in stats))], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
 
@@ -378,6 +389,9 @@ def main():
         scratch = torch.zeros_like(rgb_sum)
         rgb_mean.copy_(last["mean"])                 # (the device is synchronised: the last frame's exchange is over)
         img = rgb_mean.cpu().numpy()
+        if os.environ.get("RT_BENCH_DUMP_IMAGE"):        # tests: the last frame's mean image (H * W * 3 float64, numpy .npy)
+            import numpy as np
+            np.save(os.environ["RT_BENCH_DUMP_IMAGE"], img)
         sst = hip_render_sum(w._h, cam, min(spp, 4), 0, 1, 2024, scratch, local_rank, True)
         torch.cuda.synchronize()
         alone = None
@@ -494,8 +508,10 @@ def main():
             "scene": {"bvh_nodes": info["n_nodes"], "bvh_depth": info["bvh_depth"], "device_mb": info["device_bytes"] / 2 ** 20,
                       "bvh_build_s": info["build_seconds"], "upload_s": info["upload_seconds"], "create_s": create_s},
             "image_mean": float(img.mean()),
-            "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "rccl_world_size": dist.get_world_size() if dist.is_initialized() and not SHARE_GPU else 1,
         }
+        if SHARE_GPU:
+            out["rehearsal"] = "%d ranks share ONE GPU (gloo, sum-reduce staged through host memory): exercises the N > 1 path, measures nothing" % world
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, args.cpu_seconds)
         sys.stdout.flush()

@@ -55,12 +55,23 @@ def hip_resolve(out_sum, total_spp, device):
     return mean
 
 
-def render_distributed(render_sum, out_sum, spp, seed=0, resolve=None, side_stream=None, scaling="weak"):
+def reduce_through_host(out_sum):
+    """The sum-reduce to rank 0 for a process group whose backend has no device collectives (gloo): staged through host
+    memory.  Only for rehearsing the N > 1 path where RCCL cannot run — several ranks sharing ONE GPU (bench.py's
+    RT_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one device) — never the measured path."""
+    host = out_sum.cpu()
+    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+    if dist.get_rank() == 0:
+        out_sum.copy_(host)
+
+
+def render_distributed(render_sum, out_sum, spp, seed=0, resolve=None, side_stream=None, scaling="weak", reduce=None):
     """Every rank calls this.  render_sum(spp, offset, stride, seed, out_sum) must ADD the rank's
     per-pixel sums into out_sum (a float64 tensor, zeroed here).  Returns (mean or None, stats):
     the mean image only on rank 0.  resolve(out_sum, total_spp) -> mean: the division on rank 0 (default: a torch
     division; GPU hosts pass hip_resolve so that the library's own resolve kernel runs).
     spp / scaling: see partition() — per rank ("weak") or for the whole job ("strong").
+    reduce(out_sum): the sum-reduce to rank 0 (default: dist.reduce on out_sum where it lies — RCCL for a device tensor).
 
     side_stream (GPU hosts rendering frame after frame): the exchange step — the sum-reduce and rank 0's resolve — is
     queued on that stream behind the render, so the next frame's kernels need not wait for the collective.  The caller
@@ -74,7 +85,10 @@ def render_distributed(render_sum, out_sum, spp, seed=0, resolve=None, side_stre
 
     def exchange():
         if dist.is_initialized():
-            dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
+            if reduce is not None:
+                reduce(out_sum)
+            else:
+                dist.reduce(out_sum, dst=0, op=dist.ReduceOp.SUM)
         if rank != 0:
             return None
         return resolve(out_sum, total) if resolve else out_sum / float(total)

@@ -7,6 +7,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -78,3 +80,33 @@ def test_bench_launcher_ends_the_other_ranks_when_one_fails():
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "rank(s) failed" in r.stderr
     assert time.time() - t0 < 120
+
+
+@pytest.mark.gpu
+def test_ranks_sharing_the_gpu_render_the_single_rank_image(tmp_path):
+    """The N > 1 path with REAL renders on a one-GPU box (RT_BENCH_SHARE_GPU=1: every rank on device 0, gloo, the sum-reduce
+    staged through host memory — RCCL refuses two ranks on one device): launcher, sample partition, per-rank renders
+    through the C ABI, exchange, resolve.  Weak scaling at 2 ranks (6 + 6 samples) and strong scaling at 3 (12 = 4 + 4 + 4)
+    and at 2 with an uneven split (7 = 4 + 3) must give the single-rank image of the same sample set: the same paths
+    (equal segment counts) summed in another order (f64: 1e-12 relative)."""
+    import numpy as np
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_STANDIN")}
+    common = ["--workload", "cover", "--width", "256", "--height", "144", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alone"]
+
+    def run(tag, extra, share):
+        path = str(tmp_path / (tag + ".npy"))
+        env = dict(base, RT_BENCH_DUMP_IMAGE=path)
+        if share:
+            env["RT_BENCH_SHARE_GPU"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return _json_line(r.stdout), np.load(path)
+
+    for total, n, args in ((12, 2, ["--spp", "6"]), (12, 3, ["--spp", "12", "--scaling", "strong"]), (7, 2, ["--spp", "7", "--scaling", "strong"])):
+        one, img1 = run("one%d" % total, ["--gpus", "1", "--spp", str(total)], False)
+        d, img = run("n%d_%d" % (n, total), ["--gpus", str(n)] + args, True)
+        assert d["n_gpus"] == n and d["config"]["global_spp"] == total and "rehearsal" in d and "rehearsal" not in one
+        assert d["config"]["partition"].startswith("sample index mod %d" % n)
+        assert abs(d["segments_per_sample"] - one["segments_per_sample"]) < 1e-12
+        assert img.shape == img1.shape and np.all(np.isfinite(img))
+        np.testing.assert_allclose(img, img1, rtol=1e-12, atol=0)
