@@ -13,6 +13,11 @@ per GPU is fixed as N grows ("weak", the default): the frame gets 256*N spp in t
 split over the ranks, ceil((spp - r) / N) for rank r, and the JSON line says "scaling": "strong".
 
 value = W*H*global_spp / t_step / 1e6 (Msamples/s, whole job), inputs resident in HBM.
+
+The K timed steps are K complete frames, queued one behind the other (rt_opts.flags = RT_OPT_PIPELINED: a frame's first
+passes start on the GPU while the last passes of the frame before are in their sparse late bounces) and all finished —
+rt_scene_sync, then the barrier — inside the timed region; RT_BENCH_PIPELINED=0 waits for every frame before queueing
+the next (2-3 % slower on the headline scene).  Defaults: 10 steps after 2 warm-up steps (0.7 s timed).
 """
 import argparse
 import ctypes as C
@@ -33,8 +38,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="heightfield_1m", choices=["heightfield_1m", "cover", "textured_5m", "large_20m"])
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel: per GPU (weak) or of the whole job (strong); default: the config's")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -221,6 +226,9 @@ STANDIN = os.environ.get("RT_BENCH_STANDIN") == "1"
 # memory (rt_amd.distributed.reduce_through_host).  It checks the partition + exchange + launcher with real renders; its
 # JSON line says "rehearsal": its value is N ranks time-slicing one GPU and measures nothing.
 SHARE_GPU = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+# RT_BENCH_PIPELINED=0 (A/B): every step waits for its frame before the next one is queued (rt_opts.flags without
+# RT_OPT_PIPELINED) — the library's behaviour for hosts that do not ask for more.
+PIPELINED = os.environ.get("RT_BENCH_PIPELINED", "1") != "0"
 
 
 def standin_main(args, rank, world):
@@ -338,7 +346,7 @@ def main():
     def step(collect=False, spp_override=None):
         """One pass of the hot path: render this rank's sample indices, RCCL sum-reduce, resolve."""
         def render_sum(n_spp, offset, stride, seed, out_sum):
-            return hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect)
+            return hip_render_sum(w._h, cam, n_spp, offset, stride, seed, out_sum, local_rank, collect, pipelined=PIPELINED)
 
         b = last["k"] % len(sums)
         last["k"] += 1
@@ -356,9 +364,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    w.sync()                                      # (the warm-up frames' statistics stay out of the timed ones)
     barrier()
     t0 = time.perf_counter()
     stats = [st_ for st_ in (step() for _ in range(args.steps)) if st_ is not None]      # (None: a rank beyond the sample count)
+    # RT_OPT_PIPELINED: a step queues its frame behind the one before and returns; every frame — and its exchange — has
+    # finished when the region ends: rt_scene_sync waits for the frames (and brings the statistics the calls could not
+    # have yet), the barrier for the device.
+    stats.append(w.sync())
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -507,6 +520,8 @@ def main():
             "trace_fraction_of_step": (prim_s + bounce_s) / dt, "shade_fraction_of_step": shade_s / dt, "tail_fraction_of_step": tail_s / dt,
             "scene": {"bvh_nodes": info["n_nodes"], "bvh_depth": info["bvh_depth"], "device_mb": info["device_bytes"] / 2 ** 20,
                       "bvh_build_s": info["build_seconds"], "upload_s": info["upload_seconds"], "create_s": create_s},
+            "frames": "pipelined (RT_OPT_PIPELINED: a frame is queued behind the one before, all finished inside the timed region)" if PIPELINED
+                      else "one at a time",
             "image_mean": float(img.mean()),
             "rccl_world_size": dist.get_world_size() if dist.is_initialized() and not SHARE_GPU else 1,
         }

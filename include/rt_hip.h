@@ -128,6 +128,15 @@ typedef struct rt_opts {
 /* rt_render_multi only: exchange the per-device sums as f32 (half the xGMI bytes: 24.9 MB per device at 1080p, 99.5 MB
  * at 4K); every device still accumulates its own samples in f64, only the cross-device addition is f32. */
 #define RT_OPT_REDUCE_F32 1u
+/* rt_render_accumulate_device only (the other entries ignore it): queue the frame and return without waiting for it.
+ * `stream` is made to wait for the frame's last kernel, so whatever the caller queues on it afterwards (a reduce, a
+ * resolve, a copy) sees the complete sums; the next pipelined frame of the same shape starts on the scene's streams
+ * while this one's last passes are still in their sparse late bounces (1.5 ms per frame at 1080p in which the GPU is
+ * otherwise nearly idle).  The host still blocks inside a call whenever it is four passes ahead of the device.  The
+ * stats of such a call hold what was known when it returned (its launches and camera rays, and the timings of the
+ * passes — possibly of the frame before — it saw finish); the bounce counters and the remaining timings arrive with
+ * rt_scene_sync.  Every other entry point on the scene waits for the queued frames first. */
+#define RT_OPT_PIPELINED 2u
 
 typedef struct rt_stats {
     uint64_t samples;        /* camera paths traced                                     */
@@ -228,6 +237,10 @@ int rt_render(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
  * scene, and on one device, are serialised inside the library: the scene owns the path workspaces. */
 int rt_render_accumulate_device(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
                                 double* d_rgb_sum, void* stream, rt_stats* stats);
+/* Waits until every frame queued on the scene with RT_OPT_PIPELINED has finished and puts the timings and counters
+ * no call has reported yet into *stats (may be NULL).  Returns at once when nothing is queued.  No counterpart in the
+ * reference, whose render_image (src/camera.rs:327-341) returns the finished image. */
+int rt_scene_sync(const rt_scene* scene, rt_stats* stats);
 /* d_rgb_mean[i] = d_rgb_sum[i] / total_spp (src/camera.rs:324); in place allowed. */
 int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_values,
                       uint64_t total_spp, int device, void* stream);

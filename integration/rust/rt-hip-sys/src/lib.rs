@@ -56,6 +56,8 @@ pub struct RtOpts { pub spp: u32, pub sample_offset: u32, pub sample_stride: u32
                     pub device: i32, pub max_paths_in_flight: u32, pub collect_stats: u32, pub flags: u32 }
 /// `RtOpts::flags`: rt_render_multi exchanges the per-device sums as f32 (RT_OPT_REDUCE_F32)
 pub const RT_OPT_REDUCE_F32: u32 = 1;
+/// `RtOpts::flags`: rt_render_accumulate_device queues the frame and returns; rt_scene_sync waits (RT_OPT_PIPELINED)
+pub const RT_OPT_PIPELINED: u32 = 2;
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct RtStats {
     pub samples: u64, pub ray_segments: u64, pub nodes_visited: u64, pub prims_tested: u64,
@@ -114,6 +116,7 @@ extern "C" {
                      stats: *mut RtStats) -> c_int;
     pub fn rt_render_accumulate_device(scene: *const RtScene, cam: *const RtCamera, opts: *const RtOpts, d_rgb_sum: *mut f64,
                                        stream: *mut c_void, stats: *mut RtStats) -> c_int;
+    pub fn rt_scene_sync(scene: *const RtScene, stats: *mut RtStats) -> c_int;
     pub fn rt_resolve_device(d_rgb_sum: *const f64, d_rgb_mean: *mut f64, n_values: usize, total_spp: u64, device: c_int,
                              stream: *mut c_void) -> c_int;
     pub fn rt_render_multi(scenes: *const *mut RtScene, n_devices: u32, cam: *const RtCamera, opts: *const RtOpts,

@@ -35,6 +35,7 @@ opts_dt = np.dtype([("spp", "<u4"), ("sample_offset", "<u4"), ("sample_stride", 
                     ("precision", "<u4"), ("seed", "<u8"), ("device", "<i4"),
                     ("max_paths_in_flight", "<u4"), ("collect_stats", "<u4"), ("flags", "<u4")])
 OPT_REDUCE_F32 = 1
+OPT_PIPELINED = 2
 stats_dt = np.dtype([("samples", "<u8"), ("ray_segments", "<u8"), ("nodes_visited", "<u8"),
                      ("prims_tested", "<u8"), ("passes", "<u4"), ("launches", "<u4"),
                      ("seconds_trace", "<f8"), ("seconds_shade", "<f8"), ("seconds_total", "<f8"),

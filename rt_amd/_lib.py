@@ -40,6 +40,7 @@ def lib():
     L.rt_trace_primary.argtypes = [vp, vp, u32, i32, u64, vp, vp]
     L.rt_render.argtypes = [vp, vp, vp, vp, vp]
     L.rt_render_accumulate_device.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.rt_scene_sync.argtypes = [vp, vp]
     L.rt_resolve_device.argtypes = [vp, vp, sz, u64, i32, vp]
     L.rt_encode_gamma8.argtypes = [vp, sz, vp]
     L.rt_encode_gamma8_device.argtypes = [vp, sz, vp, i32, vp]
@@ -56,7 +57,7 @@ def lib():
 EXPORTS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_get_info", "rt_trace_closest", "rt_trace_closest_noalloc", "rt_trace_primary", "rt_render",
-    "rt_render_accumulate_device", "rt_resolve_device", "rt_encode_gamma8", "rt_encode_gamma8_device",
+    "rt_render_accumulate_device", "rt_scene_sync", "rt_resolve_device", "rt_encode_gamma8", "rt_encode_gamma8_device",
     "rt_render_pass", "rt_render_multi",
 ]
 

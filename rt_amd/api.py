@@ -374,6 +374,12 @@ class World:
         check(lib().rt_trace_closest(self._h, _abi.ptr(r), len(r), t_min, t_max, _abi.ptr(out), _abi.ptr(st)))
         return (out, st[0]) if with_stats else out
 
+    def sync(self):
+        """rt_scene_sync: waits for the frames queued with opts(pipelined=True); returns the stats no call has reported yet."""
+        st = _abi.one(_abi.stats_dt)
+        check(lib().rt_scene_sync(self._h, _abi.ptr(st)))
+        return st[0]
+
     def close(self):
         if self._h:
             lib().rt_scene_destroy(self._h)
@@ -431,9 +437,11 @@ class Camera:
     max_depth = property(lambda self: int(self.rec["max_depth"][0]))
 
     def opts(self, spp=None, sample_offset=0, sample_stride=1, seed=0, device=0, max_paths_in_flight=0,
-             collect_stats=False, reduce_f32=False):
+             collect_stats=False, reduce_f32=False, pipelined=False):
         o = _abi.one(_abi.opts_dt)
-        o["flags"] = _abi.OPT_REDUCE_F32 if reduce_f32 else 0      # rt_render_multi only: f32 exchange of the per-device sums
+        # reduce_f32: rt_render_multi only, f32 exchange of the per-device sums; pipelined: rt_render_accumulate_device
+        # only, the frame is queued and not waited for (World.sync / rt_scene_sync waits)
+        o["flags"] = (_abi.OPT_REDUCE_F32 if reduce_f32 else 0) | (_abi.OPT_PIPELINED if pipelined else 0)
         o["spp"] = self.samples_per_pixel if spp is None else spp
         o["sample_offset"], o["sample_stride"] = sample_offset, sample_stride
         o["precision"], o["seed"], o["device"] = 64, seed, device

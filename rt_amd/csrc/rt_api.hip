@@ -218,6 +218,20 @@ struct rt_scene {
     hipStream_t mg_stream = nullptr;
     Tuning tune;                     // the switches as the running call read them (refresh_tuning)
     LaunchCtx lctx;                  // what the walk launchers keep for this scene's device
+    // RT_OPT_PIPELINED: passes of a frame that was queued but not waited for (render_into).  While `valid`, the pipes'
+    // streams may still be running them: every entry point that touches the scene drains them first (drain_pending),
+    // except a pipelined render of the same shape, which queues its passes behind them.
+    struct Pending {
+        bool valid = false;
+        int n_pipes = 0;
+        uint32_t per_pass = 0, max_depth = 0;
+        size_t npix = 0;
+        uint32_t spp = 0, cap = 0;                           // what the pass size and the pipe count were derived from,
+        int tune_pipes = 0, tune_paths = 0;                  // ... besides npix
+        bool want_stats = false;
+        int prev_pipe = -1;                                  // pipe of the frame's last pass (its ev_acc ends the frame)
+        struct { bool in_flight = false; uint32_t n = 0, tail_depth = 0; } pipe[MAX_PIPES];
+    } pend;
 };
 
 namespace {
@@ -532,6 +546,120 @@ int ensure_pipe_streams(rt_scene* sc, int n_pipes) {
 
 // The wavefront loop.  Adds this call's per-pixel radiance sums to d_rgb_sum (device).
 //
+// Event timings of the pass a pipe has finished (phases: camera rays | first-bounce traversal | its shading | every
+// deeper bounce: stand-alone pairs, then the persistent kernel | sums), what it reported about its queues (sizes the
+// next launches), and the switch depth of the persistent kernel that follows from them.  Waits for the pass.
+constexpr uint32_t TAIL_MAX_PATHS = 1u << 15;
+int collect_pass(rt_scene* sc, Workspace& w, bool& in_flight, uint32_t n_paths, uint32_t td, int td_env, uint32_t max_depth, rt_stats& st) {
+    if (!in_flight) return RT_OK;
+    HIPCHK(hipEventSynchronize(w.ev[5]));
+    float ms[5];
+    for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], w.ev[i], w.ev[i + 1]));
+    st.seconds_trace_primary += ms[0] * 1e-3;
+    st.seconds_trace_bounce += ms[1] * 1e-3;
+    st.seconds_trace += (ms[0] + ms[1]) * 1e-3;
+    st.seconds_shade += (ms[2] + ms[4]) * 1e-3;
+    st.seconds_tail += ms[3] * 1e-3;
+    for (int d = 1; d < HIST_DEPTHS; ++d)          // what this pass reported: the next launches are sized by it
+        if (w.h_hist[d] && n_paths) sc->alive_ratio[d] = (double)w.h_hist[d] / (double)n_paths;
+    if (td_env <= 0 && td == sc->tail_depth && td < (uint32_t)HIST_DEPTHS) {
+        const uint32_t cap = std::min<uint32_t>((uint32_t)HIST_DEPTHS - 1u, std::max(2u, max_depth));
+        if (w.h_hist[td] > TAIL_MAX_PATHS && td < cap) {
+            uint32_t more = 1;
+            double r = 0.5;                                                            // paths that survive a bounce
+            if (td >= 2 && w.h_hist[td - 1] > w.h_hist[td]) {
+                r = (double)w.h_hist[td] / (double)w.h_hist[td - 1];
+                more = (uint32_t)std::ceil(std::log((double)TAIL_MAX_PATHS / (double)w.h_hist[td]) / std::log(r));
+            }
+            sc->tail_depth = std::min(cap, td + std::max(1u, more));
+            // the stand-alone launches of the depths in between are sized by the same extrapolation until they report
+            for (uint32_t d = td + 1; d <= sc->tail_depth && d < (uint32_t)HIST_DEPTHS; ++d)
+                if (!(sc->alive_ratio[d] > 0.0)) sc->alive_ratio[d] = sc->alive_ratio[d - 1] * r;
+        } else if (td > 2 && w.h_hist[td - 1] < TAIL_MAX_PATHS / 4) {
+            sc->tail_depth = td - 1;
+        }
+    }
+    in_flight = false;
+    return RT_OK;
+}
+
+// The pipes' segment counters (and, with collect_stats, the visit counters), read back into h_stat, added to st.
+void add_counters(rt_scene* sc, int n_pipes, bool want_stats, rt_stats& st) {
+    for (int k = 0; k < n_pipes; ++k) {
+        const unsigned long long* h = sc->ws[k].h_stat;
+        const unsigned long long* hp = h + STAT_GROUP * STAT_GROUP_PRIMARY;
+        const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
+        const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
+        const unsigned long long* hd = h + STAT_GROUP * STAT_GROUP_DEEP;
+        st.bounce_segments += hb_[STAT_SEGMENTS];
+        st.tail_segments += ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
+        st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
+        if (want_stats) {
+            st.nodes_visited += hp[STAT_NODES] + hb_[STAT_NODES] + ht[STAT_NODES] + hd[STAT_NODES];
+            st.prims_tested += hp[STAT_PRIMS] + hb_[STAT_PRIMS] + ht[STAT_PRIMS] + hd[STAT_PRIMS];
+            st.nodes_visited_primary += hp[STAT_NODES];
+            st.prims_tested_primary += hp[STAT_PRIMS];
+            st.nodes_visited_bounce += hb_[STAT_NODES];
+            st.prims_tested_bounce += hb_[STAT_PRIMS];
+            st.wave_node_fetches_primary += hp[STAT_WAVE_NODES];
+            st.wave_prim_fetches_primary += hp[STAT_WAVE_PRIMS];
+            if (sc->tune.debug) {      // bounce launches: lane steps / (64 x wave loop iterations)
+                fprintf(stderr, "[rt_hip] pipe %d camera rays: %llu node records fetched per wave-launch, %llu of them dead ends "
+                        "(no ray entered a child), %llu primitive records\n", k, hp[STAT_WAVE_NODES], hp[STAT_LEAVES], hp[STAT_WAVE_PRIMS]);
+                fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
+                        k, hb_[STAT_NODES], hb_[STAT_LEAVES], hb_[STAT_ITERS],
+                        hb_[STAT_ITERS] ? (double)(hb_[STAT_NODES] + hb_[STAT_LEAVES]) / (64.0 * (double)hb_[STAT_ITERS]) : 0.0);
+            }
+        }
+    }
+}
+
+// Waits for the passes a pipelined frame left in flight (rt_scene::Pending) and adds their timings and counters to
+// *st (may be null).  With the scene's device current and its mutex held; every entry point that touches the scene's
+// workspaces or streams calls it first.  On a HIP error the pipes are still synchronised one by one and the state cleared.
+int drain_pending(rt_scene* sc, rt_stats* st_out) {
+    if (!sc->pend.valid) return RT_OK;
+    rt_scene::Pending& pd = sc->pend;
+    pd.valid = false;
+    rt_stats st;
+    memset(&st, 0, sizeof(st));
+    int first_err = RT_OK;
+    for (int k = 0; k < pd.n_pipes; ++k) {
+        hipError_t e = hipMemcpyAsync(sc->ws[k].h_stat, sc->ws[k].stat_counters, STAT_BYTES, hipMemcpyDeviceToHost, sc->aux_stream[k]);
+        if (e == hipSuccess) e = hipStreamSynchronize(sc->aux_stream[k]);
+        if (e != hipSuccess && !first_err) {
+            (void)hipGetLastError();
+            first_err = fail(RT_ERR_HIP, "pipelined render: %s on pipe %d", hipGetErrorName(e), k);
+        }
+    }
+    if (first_err) return first_err;
+    for (int k = 0; k < pd.n_pipes; ++k) {
+        bool in_flight = pd.pipe[k].in_flight;
+        if (int rc = collect_pass(sc, sc->ws[k], in_flight, pd.pipe[k].n, pd.pipe[k].tail_depth, sc->tune.tail_depth, pd.max_depth, st)) return rc;
+        pd.pipe[k].in_flight = false;
+    }
+    add_counters(sc, pd.n_pipes, pd.want_stats, st);
+    if (st_out) {
+        st_out->seconds_trace_primary += st.seconds_trace_primary;
+        st_out->seconds_trace_bounce += st.seconds_trace_bounce;
+        st_out->seconds_trace += st.seconds_trace;
+        st_out->seconds_shade += st.seconds_shade;
+        st_out->seconds_tail += st.seconds_tail;
+        st_out->bounce_segments += st.bounce_segments;
+        st_out->tail_segments += st.tail_segments;
+        st_out->ray_segments += st.ray_segments;
+        st_out->nodes_visited += st.nodes_visited;
+        st_out->prims_tested += st.prims_tested;
+        st_out->nodes_visited_primary += st.nodes_visited_primary;
+        st_out->prims_tested_primary += st.prims_tested_primary;
+        st_out->nodes_visited_bounce += st.nodes_visited_bounce;
+        st_out->prims_tested_bounce += st.prims_tested_bounce;
+        st_out->wave_node_fetches_primary += st.wave_node_fetches_primary;
+        st_out->wave_prim_fetches_primary += st.wave_prim_fetches_primary;
+    }
+    return RT_OK;
+}
+
 // A pass = per_pass samples of every pixel.  Its kernels are queued on one stream WITHOUT any host round trip:
 //   depth 0      k_trace_packet<GEN, FUSE>   camera rays: generate, trace (coherent waves), shade, compact -> queue + counts A
 //   depth 1      k_walk                      first bounce: per-lane BVH4 traversal of that queue (the dominant kernel)
@@ -554,6 +682,17 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
                     (unsigned long long)last, RT_MAX_SAMPLE_INDEX);
     const size_t npix = (size_t)cam->width * cam->height;
     const Tuning& tune = sc->tune;
+    rt_stats st;
+    memset(&st, 0, sizeof(st));
+    const bool want_stats = opts->collect_stats != 0;
+    int rc;
+    // Passes of a pipelined frame may still be running (below): another pipelined frame of the same shape goes behind
+    // them, anything else waits for them first — before any workspace is looked at, let alone outgrown and freed.
+    if (sc->pend.valid && !((opts->flags & RT_OPT_PIPELINED) && sc->pend.npix == npix && sc->pend.spp == opts->spp &&
+                            sc->pend.cap == opts->max_paths_in_flight && sc->pend.tune_pipes == tune.pipes &&
+                            sc->pend.tune_paths == tune.paths_log2 && sc->pend.want_stats == want_stats &&
+                            sc->pend.max_depth == cam->max_depth))
+        if ((rc = drain_pending(sc, &st))) return rc;
     const int pfe = tune.paths_log2;                               // experiments: log2 of the default cap
     size_t dflt = pfe >= 10 && pfe <= 30 ? size_t(1) << pfe : DEFAULT_PATHS_IN_FLIGHT;
     // A frame of fewer than four default-sized passes (a rank's share of a strong-scaling job, a preview) cannot keep four
@@ -570,7 +709,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const uint32_t want_pipes = pe >= 1 ? (uint32_t)std::min(pe, MAX_PIPES) : (uint32_t)DEFAULT_PIPES;
     uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
     int n_pipes = (int)std::min<uint32_t>(n_passes, want_pipes);
-    int rc;
     // Workspaces: n_pipes x (per_pass x pixels) paths.  When the device cannot hold them (a shared or smaller-HBM GPU) the
     // render goes on with fewer passes in flight, then with smaller passes, instead of failing.
     {
@@ -647,9 +785,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const int ge = tune.group;
     const uint32_t group_cap = ge > 0 ? (uint32_t)ge : 16u;
 
-    rt_stats st;
-    memset(&st, 0, sizeof(st));
-    const bool want_stats = opts->collect_stats != 0;
     const bool use_packet = !tune.no_packet && packet_supported(sc->d);
     const bool fuse_shade = use_packet && !tune.no_fuse;      // depth-0 shading inside the camera-ray kernel
     // Depth from which the persistent trace-and-shade kernel takes over.  Stand-alone k_walk + k_shade launches are the
@@ -659,7 +794,6 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     // read from the reported sizes where a stand-alone pair ran, extrapolated with the last decay ratio beyond them (the
     // persistent kernel reports only the size it starts with) — and comes back one depth when the last stand-alone pair
     // saw fewer than a quarter of that.  RT_HIP_TAIL_DEPTH=<d> fixes it (tests, A/B).  The image does not depend on it.
-    constexpr uint32_t TAIL_MAX_PATHS = 1u << 15;
     const int td_env = tune.tail_depth;
     auto tail_depth_now = [&]() -> uint32_t { return td_env > 0 ? (uint32_t)td_env : sc->tail_depth; };
     const int stagger_mode = tune.stagger;
@@ -676,59 +810,47 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         pipes[k].w = &sc->ws[k];
         pipes[k].s = n_pipes > 1 ? sc->aux_stream[k] : stream;
     }
+    // RT_OPT_PIPELINED (include/rt_hip.h): the frame is queued and not waited for, and a frame of the same shape queued
+    // behind it starts on the pipes while the last passes of this one are still in their low-occupancy bounces — the
+    // ~1.5 ms at the end of every frame in which the GPU is nearly idle.  Only the sums touch the caller's buffer: the
+    // frame's first k_accumulate waits for what the caller had queued on `stream` (the others follow it in pass order),
+    // and at the end `stream` is made to wait for the last one.
+    const bool pipelined = (opts->flags & RT_OPT_PIPELINED) != 0 && n_pipes > 1;
+    if (sc->pend.valid && !(pipelined && sc->pend.n_pipes == n_pipes && sc->pend.per_pass == per_pass))      // (memory ran short meanwhile)
+        if ((rc = drain_pending(sc, &st))) return rc;
+    const bool continuing = sc->pend.valid;      // (then: same pipes, same pass size, their streams order the workspaces' reuse)
+    int prev_pipe = -1;
+    if (continuing) {
+        for (int k = 0; k < n_pipes; ++k) {
+            pipes[k].in_flight = sc->pend.pipe[k].in_flight;
+            pipes[k].n = sc->pend.pipe[k].n;
+            pipes[k].tail_depth = sc->pend.pipe[k].tail_depth;
+        }
+        prev_pipe = sc->pend.prev_pipe;
+        sc->pend.valid = false;                  // (this call owns the passes now; set again when it leaves them in flight)
+    }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
         HIPCHK(hipEventRecord(sc->ev_fork, stream));
-        for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
+        if (!pipelined)
+            for (int k = 0; k < n_pipes; ++k) HIPCHK(hipStreamWaitEvent(sc->aux_stream[k], sc->ev_fork, 0));
     }
-    for (int k = 0; k < n_pipes; ++k) {
-        // queue counters start at zero (every pass leaves them cleared again: k_accumulate), statistics too
-        HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
-        HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
-    }
+    if (!continuing)
+        for (int k = 0; k < n_pipes; ++k) {
+            // queue counters start at zero (every pass leaves them cleared again: k_accumulate), statistics too
+            // (a frame queued behind a pipelined one finds both as it needs them: the statistics run on until they are read)
+            HIPCHK(hipMemsetAsync(pipes[k].w->counters, 0, 2 * COUNTER_BYTES + HIST_BYTES, pipes[k].s));
+            HIPCHK(hipMemsetAsync(pipes[k].w->stat_counters, 0, STAT_BYTES, pipes[k].s));
+        }
     const double t0 = now_s();
 
-    // event timings of the pass a pipe has finished (phases: camera rays | first-bounce traversal | its shading | every
-    // deeper bounce: stand-alone pairs, then the persistent kernel | sums)
     auto collect = [&](Pipe& P) -> int {
-        if (!P.in_flight) return RT_OK;
-        Workspace& w = *P.w;
-        HIPCHK(hipEventSynchronize(w.ev[5]));
-        float ms[5];
-        for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], w.ev[i], w.ev[i + 1]));
-        st.seconds_trace_primary += ms[0] * 1e-3;
-        st.seconds_trace_bounce += ms[1] * 1e-3;
-        st.seconds_trace += (ms[0] + ms[1]) * 1e-3;
-        st.seconds_shade += (ms[2] + ms[4]) * 1e-3;
-        st.seconds_tail += ms[3] * 1e-3;
-        for (int d = 1; d < HIST_DEPTHS; ++d)          // what this pass reported: the next launches are sized by it
-            if (w.h_hist[d] && P.n) sc->alive_ratio[d] = (double)w.h_hist[d] / (double)P.n;
-        const uint32_t td = P.tail_depth;
-        if (td_env <= 0 && td == sc->tail_depth && td < (uint32_t)HIST_DEPTHS) {
-            const uint32_t cap = std::min<uint32_t>((uint32_t)HIST_DEPTHS - 1u, std::max(2u, cam->max_depth));
-            if (w.h_hist[td] > TAIL_MAX_PATHS && td < cap) {
-                uint32_t more = 1;
-                double r = 0.5;                                                            // paths that survive a bounce
-                if (td >= 2 && w.h_hist[td - 1] > w.h_hist[td]) {
-                    r = (double)w.h_hist[td] / (double)w.h_hist[td - 1];
-                    more = (uint32_t)std::ceil(std::log((double)TAIL_MAX_PATHS / (double)w.h_hist[td]) / std::log(r));
-                }
-                sc->tail_depth = std::min(cap, td + std::max(1u, more));
-                // the stand-alone launches of the depths in between are sized by the same extrapolation until they report
-                for (uint32_t d = td + 1; d <= sc->tail_depth && d < (uint32_t)HIST_DEPTHS; ++d)
-                    if (!(sc->alive_ratio[d] > 0.0)) sc->alive_ratio[d] = sc->alive_ratio[d - 1] * r;
-            } else if (td > 2 && w.h_hist[td - 1] < TAIL_MAX_PATHS / 4) {
-                sc->tail_depth = td - 1;
-            }
-        }
-        P.in_flight = false;
-        return RT_OK;
+        return collect_pass(sc, *P.w, P.in_flight, P.n, P.tail_depth, td_env, cam->max_depth, st);
     };
     auto estimate = [&](uint32_t depth, uint32_t n) -> uint32_t {
         if (depth >= (uint32_t)HIST_DEPTHS || !(sc->alive_ratio[depth] > 0.0)) return 0u;
         return (uint32_t)std::min<double>((double)n, sc->alive_ratio[depth] * (double)n + 1.0);
     };
 
-    int prev_pipe = -1;
     // queues one pass on its pipe; a failure in here leaves the other pipes' work in flight: the caller drains them all
     auto queue_pass = [&](uint32_t pass) -> int {
         const int k = (int)(pass % (uint32_t)n_pipes);
@@ -759,6 +881,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         // Ramp: the first pass of every pipe starts when the pass before it has traced its camera rays, so that the pipes
         // run out of phase (the coherent camera rays of one pass share the GPU with the incoherent bounces of another);
         // after that every pipe runs free.  RT_HIP_STAGGER=0: no ramp, =2: every pass waits (strict camera chain).
+        // (Also for a frame queued behind a pipelined one, whose pipes are out of phase already: without the ramp there
+        // the 1 M-triangle scene renders at 7790-7880 instead of 7950 Msamples/s.)
         if (stagger && prev_pipe >= 0 && prev_pipe != k && (pass < (uint32_t)n_pipes || stagger_mode == 2))
             HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
         HIPCHK(hipEventRecord(w.ev[0], P.s));
@@ -813,6 +937,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         HIPCHK(hipEventRecord(w.ev[4], ws));
         // ---- radiance sums are added pass by pass in pass order (bit-reproducible), whichever pipe is first
         if (prev_pipe >= 0 && prev_pipe != k) HIPCHK(hipStreamWaitEvent(ws, sc->ev_acc[prev_pipe], 0));
+        if (pipelined && pass == 0) HIPCHK(hipStreamWaitEvent(ws, sc->ev_fork, 0));      // the caller's queued work (see above)
         launch_accumulate(pp, w.path_radiance, nl, d_rgb_sum, w.counters, (uint32_t)((2 * COUNTER_BYTES + HIST_BYTES) / 4), ws);
         HIPCHK(hipEventRecord(sc->ev_acc[k], ws));
         HIPCHK(hipEventRecord(w.ev[5], ws));
@@ -831,6 +956,29 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     std::string loop_err;
     for (uint32_t pass = 0; pass < n_passes && !loop_rc; ++pass)
         if ((loop_rc = queue_pass(pass))) loop_err = g_err;
+    if (pipelined && !loop_rc) {
+        // The frame is complete when its last k_accumulate is (the sums run in pass order, and a pass's sum is its last
+        // kernel): the caller's stream waits for that one, and the passes stay in flight for the next call to find.
+        hipError_t e = hipStreamWaitEvent(stream, sc->ev_acc[prev_pipe], 0);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) {
+            rt_scene::Pending& pd = sc->pend;
+            pd.valid = true;
+            pd.n_pipes = n_pipes; pd.per_pass = per_pass; pd.max_depth = cam->max_depth; pd.npix = npix;
+            pd.spp = opts->spp; pd.cap = opts->max_paths_in_flight; pd.tune_pipes = tune.pipes; pd.tune_paths = tune.paths_log2;
+            pd.want_stats = want_stats; pd.prev_pipe = prev_pipe;
+            for (int k = 0; k < n_pipes; ++k) {
+                pd.pipe[k].in_flight = pipes[k].in_flight; pd.pipe[k].n = pipes[k].n; pd.pipe[k].tail_depth = pipes[k].tail_depth;
+            }
+            st.seconds_total = now_s() - t0;          // (host time to queue the frame)
+            st.ray_segments += st.primary_segments;   // (the bounce counters come with the call that waits: rt_scene_sync or any other)
+            if (stats) *stats = st;
+            return RT_OK;
+        }
+        (void)hipGetLastError();
+        loop_rc = fail(RT_ERR_HIP, "render: %s", hipGetErrorName(e));
+        loop_err = g_err;
+    }
     // Drain EVERY pipe before returning, whatever happened while queueing or on another pipe: the kernels in flight read
     // and write the scene's workspaces and the caller's sum buffer, and the next call on this scene reuses both.
     int first_err = RT_OK;
@@ -858,34 +1006,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         for (int d = 1; d < HIST_DEPTHS && pipes[0].w->h_hist[d]; ++d) fprintf(stderr, " %u", pipes[0].w->h_hist[d]);
         fprintf(stderr, "\n");
     }
-    st.ray_segments = st.primary_segments;
-    for (int k = 0; k < n_pipes; ++k) {
-        const unsigned long long* h = pipes[k].w->h_stat;
-        const unsigned long long* hp = h + STAT_GROUP * STAT_GROUP_PRIMARY;
-        const unsigned long long* hb_ = h + STAT_GROUP * STAT_GROUP_BOUNCE;
-        const unsigned long long* ht = h + STAT_GROUP * STAT_GROUP_TAIL;
-        const unsigned long long* hd = h + STAT_GROUP * STAT_GROUP_DEEP;
-        st.bounce_segments += hb_[STAT_SEGMENTS];
-        st.tail_segments += ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
-        st.ray_segments += hb_[STAT_SEGMENTS] + ht[STAT_SEGMENTS] + hd[STAT_SEGMENTS];
-        if (want_stats) {
-            st.nodes_visited += hp[STAT_NODES] + hb_[STAT_NODES] + ht[STAT_NODES] + hd[STAT_NODES];
-            st.prims_tested += hp[STAT_PRIMS] + hb_[STAT_PRIMS] + ht[STAT_PRIMS] + hd[STAT_PRIMS];
-            st.nodes_visited_primary += hp[STAT_NODES];
-            st.prims_tested_primary += hp[STAT_PRIMS];
-            st.nodes_visited_bounce += hb_[STAT_NODES];
-            st.prims_tested_bounce += hb_[STAT_PRIMS];
-            st.wave_node_fetches_primary += hp[STAT_WAVE_NODES];
-            st.wave_prim_fetches_primary += hp[STAT_WAVE_PRIMS];
-            if (tune.debug) {      // bounce launches: lane steps / (64 x wave loop iterations)
-                fprintf(stderr, "[rt_hip] pipe %d camera rays: %llu node records fetched per wave-launch, %llu of them dead ends "
-                        "(no ray entered a child), %llu primitive records\n", k, hp[STAT_WAVE_NODES], hp[STAT_LEAVES], hp[STAT_WAVE_PRIMS]);
-                fprintf(stderr, "[rt_hip] pipe %d bounce: node steps %llu, leaf steps %llu, wave iterations %llu -> lane occupancy %.3f\n",
-                        k, hb_[STAT_NODES], hb_[STAT_LEAVES], hb_[STAT_ITERS],
-                        hb_[STAT_ITERS] ? (double)(hb_[STAT_NODES] + hb_[STAT_LEAVES]) / (64.0 * (double)hb_[STAT_ITERS]) : 0.0);
-            }
-        }
-    }
+    st.ray_segments += st.primary_segments;      // (+=: a drained pipelined frame may have left its counters here)
+    add_counters(sc, n_pipes, want_stats, st);
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -1367,6 +1489,8 @@ void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     DeviceGuard dg;
     if (hipSetDevice(sc->device) == hipSuccess) {
+        if (sc->pend.valid)                              // passes of a pipelined frame nobody waited for
+            for (int k = 0; k < sc->pend.n_pipes; ++k) (void)hipStreamSynchronize(sc->aux_stream[k]);
         for (auto& w : sc->ws) free_workspace(w);
         for (auto& a : sc->pad_stream)
             if (a) (void)hipStreamDestroy(a);
@@ -1410,6 +1534,7 @@ int rt_trace_closest(const rt_scene* csc, const rt_ray* rays, size_t n, double t
     int rc = select_device(sc->device);
     if (rc) return rc;
     refresh_tuning(sc);
+    if ((rc = drain_pending(sc, nullptr))) return rc;      // (a pipelined frame's passes hold the workspaces)
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     if ((rc = ensure_workspace(sc, chunk))) return rc;
     Workspace& w = sc->ws[0];
@@ -1486,6 +1611,7 @@ int rt_trace_primary(const rt_scene* csc, const rt_camera* cam, uint32_t sample_
     DeviceGuard dg;
     if ((rc = select_device(sc->device))) return rc;
     refresh_tuning(sc);
+    if ((rc = drain_pending(sc, nullptr))) return rc;      // (a pipelined frame's passes hold the workspaces)
     if ((rc = ensure_workspace(sc, npix))) return rc;
     Workspace& w = sc->ws[0];
     rt_hit* d_hits = nullptr;
@@ -1539,6 +1665,17 @@ int rt_render_accumulate_device(const rt_scene* csc, const rt_camera* cam, const
     return render_into(sc, cam, opts, d_rgb_sum, (hipStream_t)stream, stats);
 }
 
+int rt_scene_sync(const rt_scene* csc, rt_stats* stats) {
+    rt_scene* sc = const_cast<rt_scene*>(csc);
+    if (!sc) return fail(RT_ERR_INVALID, "scene is NULL");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    std::lock_guard<std::mutex> dl(g_device_mu[sc->device]);
+    std::lock_guard<std::mutex> sl(sc->mu);
+    DeviceGuard dg;
+    if (int rc = select_device(sc->device)) return rc;
+    return drain_pending(sc, stats);
+}
+
 int rt_resolve_device(const double* d_rgb_sum, double* d_rgb_mean, size_t n_values, uint64_t total_spp, int device,
                       void* stream) {
     if (!d_rgb_sum || !d_rgb_mean) return fail(RT_ERR_INVALID, "NULL argument");
@@ -1568,7 +1705,9 @@ int rt_render(const rt_scene* csc, const rt_camera* cam, const rt_opts* opts, do
     if ((rc = scene_io(sc, 0, nval, &d_sum))) return rc;
     hipStream_t stream = nullptr;
     HIPCHK(hipMemsetAsync(d_sum, 0, nval * sizeof(double), stream));
-    if ((rc = render_into(sc, cam, opts, d_sum, stream, stats))) return rc;
+    rt_opts o = *opts;
+    o.flags &= ~RT_OPT_PIPELINED;                         // (this entry returns the finished image)
+    if ((rc = render_into(sc, cam, &o, d_sum, stream, stats))) return rc;
     launch_resolve(d_sum, d_sum, nval, (double)opts->spp, stream);
     HIPCHK(hipMemcpyAsync(out_rgb_mean, d_sum, nval * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));

@@ -33,11 +33,14 @@ def partition(spp, rank, world, scaling="weak"):
     return mine, rank, world, spp
 
 
-def hip_render_sum(world_handle, cam, spp, sample_offset, sample_stride, seed, out_sum, device, collect_stats=False):
-    """Adds this rank's radiance sums into the CUDA tensor out_sum through the C ABI."""
+def hip_render_sum(world_handle, cam, spp, sample_offset, sample_stride, seed, out_sum, device, collect_stats=False,
+                   pipelined=False):
+    """Adds this rank's radiance sums into the CUDA tensor out_sum through the C ABI.  pipelined: RT_OPT_PIPELINED — the
+    frame is queued behind what the current stream holds and the call returns; the stream waits for the frame, the host
+    does not (rt_scene_sync / World.sync does, and returns the rest of the stats)."""
     from ._lib import check, lib
     o = cam.opts(spp=spp, sample_offset=sample_offset, sample_stride=sample_stride, seed=seed, device=device,
-                 collect_stats=collect_stats)
+                 collect_stats=collect_stats, pipelined=pipelined)
     st = _abi.one(_abi.stats_dt)
     stream = torch.cuda.current_stream().cuda_stream
     check(lib().rt_render_accumulate_device(world_handle, _abi.ptr(cam.rec), _abi.ptr(o), C.c_void_p(out_sum.data_ptr()),

@@ -198,3 +198,83 @@ def test_streams_the_host_made_before_do_not_change_the_image(monkeypatch):
     assert np.array_equal(img, base)
     for s in made:
         hip.hipStreamDestroy(s)
+
+
+def test_pipelined_frames_equal_the_waited_ones(mixed):
+    """RT_OPT_PIPELINED: rt_render_accumulate_device queues a frame behind the one before and returns; the caller's stream
+    waits for the frame, rt_scene_sync for all of them.  Three frames (different seeds) queued back to back on a stream
+    — each behind an asynchronous clear of its buffer on that stream, the work the frame's first sum has to wait for —
+    must leave exactly the sums of the three waited renders, and the statistics of the calls plus rt_scene_sync's must
+    add up to the waited ones.  Then: an entry point that needs the workspaces while a frame is queued (World.hit), a
+    frame of another shape behind a queued one, and a scene destroyed with a frame still queued."""
+    from hip_mem import DeviceBuffer, hip, synchronize
+    desc, world = mixed
+    L, h = lib(), hip()
+    h.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    cam = scenes.cam1(128, 72, max_depth=12)
+    npix, nval = 128 * 72, 128 * 72 * 3
+    kw = dict(spp=16, max_paths_in_flight=2 * npix)              # 8 passes of 2 samples: four in flight, every pipe used twice
+
+    def waited(seed, **over):
+        buf = DeviceBuffer(nval * 8)
+        buf.fill(0)
+        st = _abi.one(_abi.stats_dt)
+        o = cam.opts(seed=seed, **dict(kw, **over))
+        check(L.rt_render_accumulate_device(world._h, _abi.ptr(cam.rec), _abi.ptr(o), buf.ptr, None, _abi.ptr(st)))
+        return buf.to_array(np.float64, nval), st[0]
+
+    ref = [waited(s) for s in (1, 2, 3)]
+    assert int(ref[0][1]["passes"]) == 8
+    stream = C.c_void_p()
+    assert h.hipStreamCreate(C.byref(stream)) == 0
+    bufs = [DeviceBuffer(nval * 8) for _ in range(3)]
+    for b in bufs:
+        b.fill(0xFF)                                             # garbage: the clear queued on the stream is what zeroes it
+    sts = []
+    for s, b in zip((1, 2, 3), bufs):
+        assert h.hipMemsetAsync(b.ptr, 0, nval * 8, stream) == 0
+        st = _abi.one(_abi.stats_dt)
+        o = cam.opts(seed=s, pipelined=True, **kw)
+        check(L.rt_render_accumulate_device(world._h, _abi.ptr(cam.rec), _abi.ptr(o), b.ptr, stream, _abi.ptr(st)))
+        sts.append(st[0])
+    sts.append(world.sync())
+    assert h.hipStreamSynchronize(stream) == 0
+    for (want, _), b in zip(ref, bufs):
+        assert np.array_equal(b.to_array(np.float64, nval), want)
+    for key in ("samples", "ray_segments", "primary_segments", "bounce_segments", "tail_segments", "passes"):
+        assert sum(int(x[key]) for x in sts) == sum(int(st[key]) for _, st in ref), key
+    assert int(world.sync()["ray_segments"]) == 0               # nothing queued: returns at once, all zero
+
+    # an entry point that uses the workspaces while a frame is queued waits for it first; the frame still completes
+    rays = np.zeros((64, 6))
+    rays[:, 0:3] = (13.0, 2.0, 3.0)
+    rays[:, 3:6] = np.random.default_rng(5).normal(size=(64, 3))
+    hits_before = world.hit(rays)
+    assert h.hipMemsetAsync(bufs[0].ptr, 0, nval * 8, stream) == 0
+    o = cam.opts(seed=1, pipelined=True, **kw)
+    check(L.rt_render_accumulate_device(world._h, _abi.ptr(cam.rec), _abi.ptr(o), bufs[0].ptr, stream, None))
+    assert np.array_equal(world.hit(rays), hits_before)
+    # a frame of another shape behind a queued one (waits for it, then runs on its own), then a waited frame
+    assert h.hipMemsetAsync(bufs[1].ptr, 0, nval * 8, stream) == 0
+    o = cam.opts(seed=2, pipelined=True, **kw)
+    check(L.rt_render_accumulate_device(world._h, _abi.ptr(cam.rec), _abi.ptr(o), bufs[1].ptr, stream, None))
+    assert h.hipMemsetAsync(bufs[2].ptr, 0, nval * 8, stream) == 0
+    o = cam.opts(seed=3, pipelined=True, **dict(kw, spp=10))
+    check(L.rt_render_accumulate_device(world._h, _abi.ptr(cam.rec), _abi.ptr(o), bufs[2].ptr, stream, None))
+    want10, _ = waited(3, spp=10)                                # (a waited call: drains what is queued first)
+    assert h.hipStreamSynchronize(stream) == 0
+    assert np.array_equal(bufs[0].to_array(np.float64, nval), ref[0][0])
+    assert np.array_equal(bufs[1].to_array(np.float64, nval), ref[1][0])
+    assert np.array_equal(bufs[2].to_array(np.float64, nval), want10)
+    # rt_render ignores the flag (it returns the finished image)
+    img = cam.render_image(world, seed=1, pipelined=True, **kw)
+    assert np.array_equal(img.reshape(-1) * 16.0, ref[0][0]) or np.allclose(img.reshape(-1) * 16.0, ref[0][0], rtol=1e-15, atol=0)
+    # a scene destroyed with a frame still queued
+    w2 = World.build(desc)
+    b2 = DeviceBuffer(nval * 8)
+    b2.fill(0)
+    o = cam.opts(seed=4, pipelined=True, **kw)
+    check(L.rt_render_accumulate_device(w2._h, _abi.ptr(cam.rec), _abi.ptr(o), b2.ptr, stream, None))
+    w2.close()
+    synchronize()
+    assert h.hipStreamDestroy(stream) == 0
