@@ -132,7 +132,7 @@ typedef struct rt_opts {
  * `stream` is made to wait for the frame's last kernel, so whatever the caller queues on it afterwards (a reduce, a
  * resolve, a copy) sees the complete sums; the next pipelined frame of the same shape starts on the scene's streams
  * while this one's last passes are still in their sparse late bounces (1.5 ms per frame at 1080p in which the GPU is
- * otherwise nearly idle).  The host still blocks inside a call whenever it is four passes ahead of the device.  The
+ * otherwise nearly idle; frames shorter than four passes keep four passes in flight across frames).  The host still blocks inside a call whenever it is four passes ahead of the device.  The
  * stats of such a call hold what was known when it returned (its launches and camera rays, and the timings of the
  * passes — possibly of the frame before — it saw finish); the bounce counters and the remaining timings arrive with
  * rt_scene_sync.  Every other entry point on the scene waits for the queued frames first. */

@@ -695,11 +695,13 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         if ((rc = drain_pending(sc, &st))) return rc;
     const int pfe = tune.paths_log2;                               // experiments: log2 of the default cap
     size_t dflt = pfe >= 10 && pfe <= 30 ? size_t(1) << pfe : DEFAULT_PATHS_IN_FLIGHT;
-    // A frame of fewer than four default-sized passes (a rank's share of a strong-scaling job, a preview) cannot keep four
+    // A frame of at most three default-sized passes (a rank's share of a strong-scaling job, a preview) cannot keep four
     // passes in flight: with passes of half the size the tail of one hides behind the bulk of the next again.  1080p,
     // Msamples/s with 2^26 / 2^25 / 2^24 paths per pass: 32 spp 6010 / 6680 / 6350, 64 spp 7060 / 7270 / 6740, 128 spp 7550 /
     // 7570 / 6940, 256 spp 7750 / 7640 / 6900.  (The image does not depend on the pass size: sums are in sample order.)
-    if (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp < 4 * dflt) dflt >>= 1;
+    // Pipelined frames (below) of 16 / 32 / 64 / 128 spp: 6930 / 7330 / 7850 / 8000 with this rule; 64 spp in two passes of 32: 7560.
+    const bool want_pipelined = (opts->flags & RT_OPT_PIPELINED) != 0;
+    if (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp <= 3 * dflt) dflt >>= 1;
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
     uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
@@ -708,7 +710,8 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     const int pe = tune.pipes;
     const uint32_t want_pipes = pe >= 1 ? (uint32_t)std::min(pe, MAX_PIPES) : (uint32_t)DEFAULT_PIPES;
     uint32_t n_passes = (opts->spp + per_pass - 1) / per_pass;
-    int n_pipes = (int)std::min<uint32_t>(n_passes, want_pipes);
+    // (a pipelined frame of fewer passes than pipes still gets every pipe: the frames behind it go on where it stopped)
+    int n_pipes = want_pipelined ? (int)want_pipes : (int)std::min<uint32_t>(n_passes, want_pipes);
     // Workspaces: n_pipes x (per_pass x pixels) paths.  When the device cannot hold them (a shared or smaller-HBM GPU) the
     // render goes on with fewer passes in flight, then with smaller passes, instead of failing.
     {
@@ -739,7 +742,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             per_pass = (per_pass + 1) / 2;
         }
         n_passes = (opts->spp + per_pass - 1) / per_pass;
-        n_pipes = (int)std::min<uint32_t>(n_passes, (uint32_t)n_pipes);
+        if (!want_pipelined) n_pipes = (int)std::min<uint32_t>(n_passes, (uint32_t)n_pipes);
     }
     for (int k = 0; k < n_pipes; ++k) {          // per-pass Halton tables (16 B per sample of a pass; optional: a failed allocation only disables them)
         Workspace& w = sc->ws[k];
@@ -820,6 +823,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         if ((rc = drain_pending(sc, &st))) return rc;
     const bool continuing = sc->pend.valid;      // (then: same pipes, same pass size, their streams order the workspaces' reuse)
     int prev_pipe = -1;
+    uint32_t pipe0 = 0;                          // pipe of this frame's first pass
     if (continuing) {
         for (int k = 0; k < n_pipes; ++k) {
             pipes[k].in_flight = sc->pend.pipe[k].in_flight;
@@ -827,6 +831,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             pipes[k].tail_depth = sc->pend.pipe[k].tail_depth;
         }
         prev_pipe = sc->pend.prev_pipe;
+        pipe0 = (uint32_t)(prev_pipe + 1) % (uint32_t)n_pipes;      // the pipe after the one the frame before ended on
         sc->pend.valid = false;                  // (this call owns the passes now; set again when it leaves them in flight)
     }
     if (n_pipes > 1) {   // work already queued on the caller's stream (e.g. zeroing d_rgb_sum) comes first
@@ -853,7 +858,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
 
     // queues one pass on its pipe; a failure in here leaves the other pipes' work in flight: the caller drains them all
     auto queue_pass = [&](uint32_t pass) -> int {
-        const int k = (int)(pass % (uint32_t)n_pipes);
+        const int k = (int)((pipe0 + pass) % (uint32_t)n_pipes);
         Pipe& P = pipes[k];
         if (int crc = collect(P)) return crc;        // (also: the pipe's events are free to be recorded again)
         Workspace& w = *P.w;
