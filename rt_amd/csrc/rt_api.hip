@@ -103,7 +103,7 @@ struct Tuning {
     bool stream_probe = true;     // RT_HIP_STREAM_PROBE=0: do not check that the pipes' streams sit on queues of their own
     int pipes = 0;                // RT_HIP_PIPES=<1..8>: passes in flight (default 4)
     int tail_depth = 0;           // RT_HIP_TAIL_DEPTH=<d>: depth from which the persistent kernel takes over (default: adaptive)
-    int stagger = 1;              // RT_HIP_STAGGER=0|1|2
+    int stagger = 2;              // RT_HIP_STAGGER=0|1|2 (default 2)
     int group = 0;                // RT_HIP_GROUP=1|4|16|64: cap of the samples of a pixel that share a wave
     int paths_log2 = 0;           // RT_HIP_PATHS_IN_FLIGHT=<log2>: default cap of the paths of a pass
     int hw_queues = 4;            // GPU_MAX_HW_QUEUES (HIP's own variable; 4 is its default)
@@ -128,7 +128,7 @@ Tuning read_tuning() {
     t.stream_probe = num("RT_HIP_STREAM_PROBE", 1) != 0;
     t.pipes = num("RT_HIP_PIPES", 0);
     t.tail_depth = num("RT_HIP_TAIL_DEPTH", 0);
-    t.stagger = num("RT_HIP_STAGGER", 1);
+    t.stagger = num("RT_HIP_STAGGER", 2);
     t.group = num("RT_HIP_GROUP", 0);
     t.paths_log2 = num("RT_HIP_PATHS_IN_FLIGHT", 0);
     t.hw_queues = std::max(1, num("GPU_MAX_HW_QUEUES", 4));
@@ -883,11 +883,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         unsigned long long* sg_tail = w.stat_counters + STAT_GROUP * STAT_GROUP_TAIL;
         unsigned long long* sg_deep = w.stat_counters + STAT_GROUP * STAT_GROUP_DEEP;
 
-        // Ramp: the first pass of every pipe starts when the pass before it has traced its camera rays, so that the pipes
-        // run out of phase (the coherent camera rays of one pass share the GPU with the incoherent bounces of another);
-        // after that every pipe runs free.  RT_HIP_STAGGER=0: no ramp, =2: every pass waits (strict camera chain).
-        // (Also for a frame queued behind a pipelined one, whose pipes are out of phase already: without the ramp there
-        // the 1 M-triangle scene renders at 7790-7880 instead of 7950 Msamples/s.)
+        // Camera chain: a pass starts when the pass before it (on the neighbouring pipe) has traced its camera rays, so the
+        // pipes run out of phase — the coherent camera rays of one pass share the GPU with the incoherent bounces of the
+        // others, and two camera-ray kernels never compete.  RT_HIP_STAGGER=2 (default): every pass waits; =1: only the
+        // first pass of every pipe in a frame (a ramp, after which the pipes run free); =0: no waiting.  With pipelined
+        // frames, Msamples/s for 0 / 1 / 2: S3 7770 / 7980 / 8035, S4 2355 / 2377 / 2390, S5 - / 3842 / 3909, S1 - / 7528 / 7508.
         if (stagger && prev_pipe >= 0 && prev_pipe != k && (pass < (uint32_t)n_pipes || stagger_mode == 2))
             HIPCHK(hipStreamWaitEvent(P.s, sc->ev_cam[prev_pipe], 0));
         HIPCHK(hipEventRecord(w.ev[0], P.s));
