@@ -306,6 +306,15 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     coll_dev = "cpu" if SHARE_GPU else "cuda"        # where the small tensors of the timing collectives live
+    if use_dist and not SHARE_GPU:
+        # RCCL builds its communicator — and the streams it launches on — at the first collective.  That happens here, before
+        # the scene exists and outside the render path: the library places its four pipe streams on hardware queues of
+        # their own by looking at the streams the process holds when the scene first renders (rt_api.hip:
+        # ensure_pipe_streams).
+        warm = torch.zeros(16, dtype=torch.float64, device="cuda")
+        dist.all_reduce(warm)
+        dist.reduce(warm, dst=0)
+        torch.cuda.synchronize()
 
     # RT_BENCH_EXTRA_STREAMS=<n> (A/B only): n used streams in the process before the library makes its own, as a host with
     # its own copy / collective streams would have; the library's stream set-up must make the frame rate independent of n
