@@ -233,7 +233,7 @@ int rt_render(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
  * then call rt_resolve_device once. (Extends the `.sum::<Vec3>()` of src/camera.rs:323.)
  * The call orders its work after what is already queued on `stream`, runs up to four passes at a
  * time on streams of the scene's own (placed on different hardware queues, whatever streams the host has made), and returns when all of it has finished (the host sleeps in
- * hipStreamSynchronize meanwhile: every launch of the frame is queued up front), so the buffer is complete for any stream on return.  Calls on one
+ * hipStreamSynchronize meanwhile: every launch of the frame is queued up front), so the buffer is complete for any stream on return (with RT_OPT_PIPELINED in opts->flags it returns when the frame is queued instead: see there).  Calls on one
  * scene, and on one device, are serialised inside the library: the scene owns the path workspaces. */
 int rt_render_accumulate_device(const rt_scene* scene, const rt_camera* cam, const rt_opts* opts,
                                 double* d_rgb_sum, void* stream, rt_stats* stats);
