@@ -695,13 +695,25 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
         if ((rc = drain_pending(sc, &st))) return rc;
     const int pfe = tune.paths_log2;                               // experiments: log2 of the default cap
     size_t dflt = pfe >= 10 && pfe <= 30 ? size_t(1) << pfe : DEFAULT_PATHS_IN_FLIGHT;
+    // Frames of more than 4 M pixels: a default pass would hold fewer than 16 samples per pixel, and 16 is what the layout
+    // of a pass is built around (a wave of camera rays = 16 samples of a 2 x 2 pixel block: coherent rays, k_accumulate16).
+    // The pass grows to 16 samples per pixel where four such workspaces take at most 40 % of the device's memory (4K:
+    // 133 M paths, 4 x 27 GB): config 5's frame (3840 x 2160, 20 M triangles) 3880-3920 -> 4020-4070 Msamples/s.
+    if (!(pfe >= 10 && pfe <= 30) && 16 * npix > dflt && 16 * npix < (size_t(1) << 32)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (4 * workspace_bytes(16 * npix) <= total_b / 10 * 4) dflt = 16 * npix;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     // A frame of at most three default-sized passes (a rank's share of a strong-scaling job, a preview) cannot keep four
     // passes in flight: with passes of half the size the tail of one hides behind the bulk of the next again.  1080p,
     // Msamples/s with 2^26 / 2^25 / 2^24 paths per pass: 32 spp 6010 / 6680 / 6350, 64 spp 7060 / 7270 / 6740, 128 spp 7550 /
     // 7570 / 6940, 256 spp 7750 / 7640 / 6900.  (The image does not depend on the pass size: sums are in sample order.)
     // Pipelined frames (below) of 16 / 32 / 64 / 128 spp: 6930 / 7330 / 7850 / 8000 with this rule; 64 spp in two passes of 32: 7560.
     const bool want_pipelined = (opts->flags & RT_OPT_PIPELINED) != 0;
-    if (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp <= 3 * dflt) dflt >>= 1;
+    if (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp <= 3 * dflt && (dflt >> 1) >= 16 * npix) dflt >>= 1;      // (never below 16 samples per pixel)
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
     uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
