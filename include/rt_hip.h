@@ -121,7 +121,7 @@ typedef struct rt_opts {
     uint32_t precision;      /* RT_PRECISION_F64 (0 selects it)                               */
     uint64_t seed;           /* Philox key                             */
     int32_t device;          /* HIP device ordinal                                            */
-    uint32_t max_paths_in_flight; /* 0 = library default (2^26, or 16 per pixel for frames beyond 4 M pixels where memory allows: 204 B of device memory each, for four passes in flight); paths per pass */
+    uint32_t max_paths_in_flight; /* 0 = library default (2^26; 16 per pixel for frames beyond 4 M pixels where memory allows; smaller for short frames: 204 B of device memory per path, for four passes in flight); paths per pass */
     uint32_t collect_stats;  /* 1: count nodes_visited / prims_tested (slower kernels)        */
     uint32_t flags;          /* RT_OPT_* bits (0 = defaults; was padding before: old callers pass 0) */
 } rt_opts;

@@ -699,6 +699,7 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
     // of a pass is built around (a wave of camera rays = 16 samples of a 2 x 2 pixel block: coherent rays, k_accumulate16).
     // The pass grows to 16 samples per pixel where four such workspaces take at most 40 % of the device's memory (4K:
     // 133 M paths, 4 x 27 GB): config 5's frame (3840 x 2160, 20 M triangles) 3880-3920 -> 4020-4070 Msamples/s.
+    // (2^27 paths at 1080p as well: S4 +1.5 %, S3 +-1 % from run to run — not worth 110 GB of workspaces per scene.)
     if (!(pfe >= 10 && pfe <= 30) && 16 * npix > dflt && 16 * npix < (size_t(1) << 32)) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -707,13 +708,14 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
             (void)hipGetLastError();
         }
     }
-    // A frame of at most three default-sized passes (a rank's share of a strong-scaling job, a preview) cannot keep four
-    // passes in flight: with passes of half the size the tail of one hides behind the bulk of the next again.  1080p,
+    // A frame of at most three passes (a rank's share of a strong-scaling job, a preview) cannot keep four
+    // passes in flight: with passes of half the size (and half again) the tail of one hides behind the bulk of the next again.  1080p,
     // Msamples/s with 2^26 / 2^25 / 2^24 paths per pass: 32 spp 6010 / 6680 / 6350, 64 spp 7060 / 7270 / 6740, 128 spp 7550 /
     // 7570 / 6940, 256 spp 7750 / 7640 / 6900.  (The image does not depend on the pass size: sums are in sample order.)
     // Pipelined frames (below) of 16 / 32 / 64 / 128 spp: 6930 / 7330 / 7850 / 8000 with this rule; 64 spp in two passes of 32: 7560.
     const bool want_pipelined = (opts->flags & RT_OPT_PIPELINED) != 0;
-    if (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp <= 3 * dflt && (dflt >> 1) >= 16 * npix) dflt >>= 1;      // (never below 16 samples per pixel)
+    while (!(pfe >= 10 && pfe <= 30) && npix * (size_t)opts->spp <= 3 * dflt && (dflt >> 1) >= std::max<size_t>(16 * npix, size_t(1) << 25))
+        dflt >>= 1;      // (never below 16 samples per pixel, nor below the 2^25 paths that fill the GPU)
     const size_t cap = opts->max_paths_in_flight ? opts->max_paths_in_flight : dflt;
     uint32_t per_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(opts->spp, cap / npix));
     if (npix * per_pass >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many paths in flight");
@@ -736,8 +738,11 @@ int render_into(rt_scene* sc, const rt_camera* cam, const rt_opts* opts, double*
                     if (sc->ws[k].capacity < npix * per_) add += workspace_bytes(npix * per_) - std::min(workspace_bytes(npix * per_), sc->ws[k].bytes);
                 return add;
             };
+            // (smaller passes first, down to the 2^25 paths that still fill the GPU, then fewer passes in flight)
             while (extra(n_pipes, per_pass) > free_b - free_b / 32 && !(per_pass == 1 && n_pipes == 1)) {
-                if (n_pipes > 1) --n_pipes; else per_pass = (per_pass + 1) / 2;
+                if (per_pass > 1 && npix * (size_t)per_pass > (size_t(1) << 25)) per_pass = (per_pass + 1) / 2;
+                else if (n_pipes > 1) --n_pipes;
+                else per_pass = (per_pass + 1) / 2;
             }
         } else {
             (void)hipGetLastError();
