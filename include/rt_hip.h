@@ -135,7 +135,8 @@ typedef struct rt_opts {
  * otherwise nearly idle; frames shorter than four passes keep four passes in flight across frames).  The host still blocks inside a call whenever it is four passes ahead of the device.  The
  * stats of such a call hold what was known when it returned (its launches and camera rays, and the timings of the
  * passes — possibly of the frame before — it saw finish); the bounce counters and the remaining timings arrive with
- * rt_scene_sync.  Every other entry point on the scene waits for the queued frames first. */
+ * rt_scene_sync.  Every other entry point that uses the scene's workspaces (all but rt_scene_get_info and
+ * rt_trace_closest_noalloc, which has its own scratch array) waits for the queued frames first, as does rt_scene_destroy. */
 #define RT_OPT_PIPELINED 2u
 
 typedef struct rt_stats {
